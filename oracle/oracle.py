@@ -1,0 +1,266 @@
+"""TEST INFRASTRUCTURE -- CPU oracle for the anchor-search path.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import this module.  It restates, on the CPU, what the reference computes
+on the path
+
+    find_neighbor -> find_mnn -> score_anchor/min_max -> label filter
+
+(reference files: ``scmiac/preprocessing/anchors.py:525-581, 631-679, 779-789,
+874-890, 971-987, 1021-1037`` and ``scmiac/modeling/scmiac.py:89-103``), with the
+approximate third-party index ``pynndescent.NNDescent`` (``pyproject.toml:38``,
+unpinned, not vendored) replaced by an exact search whose definition is written
+out in ``anchor_oracle.c``.  Integer work is numpy / C; the float64 score
+normalisation calls ``numpy.percentile`` exactly as the reference does.
+
+Pinning: ``tests/golden/*.npz`` were produced by running the reference's own
+``anchors.py`` / ``scmiac.py`` (loaded by path, absent third-party modules
+stubbed, this module's exact search standing in for ``NNDescent``) -- see
+``oracle/gen_golden.py``.  At the pynndescent seam itself parity is unpinned.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pandas as pd
+
+_HERE = Path(__file__).resolve().parent
+_LIB = None
+
+
+def build(force: bool = False) -> Path:
+    """Compile ``liboracle.so`` with the committed Makefile."""
+    so = _HERE / "liboracle.so"
+    if force or not so.exists() or so.stat().st_mtime < (_HERE / "anchor_oracle.c").stat().st_mtime:
+        subprocess.run(["make", "-C", str(_HERE), "-B", "liboracle.so"], check=True,
+                       stdout=subprocess.DEVNULL)
+    return so
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        so = _HERE / "liboracle.so"
+        if not so.exists():
+            build()
+        lib = ctypes.CDLL(str(so))
+        i64, i32p, f32p, i64p = (ctypes.c_int64, ctypes.POINTER(ctypes.c_int32),
+                                 ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int64))
+        lib.oracle_knn.argtypes = [f32p, i64, f32p, i64, ctypes.c_int, ctypes.c_int, i32p, f32p,
+                                   ctypes.c_int]
+        lib.oracle_knn.restype = ctypes.c_int
+        lib.oracle_find_mnn.argtypes = [i32p, i64, i64, i32p, i64, i64, ctypes.c_int, i64p]
+        lib.oracle_find_mnn.restype = i64
+        lib.oracle_snn_score.argtypes = [i64p, i64, i32p, i32p, i32p, i32p, i64, i64, i64,
+                                         ctypes.c_int, i32p]
+        lib.oracle_snn_score.restype = ctypes.c_int
+        _LIB = lib
+    return _LIB
+
+
+def _p(a, ct):
+    return a.ctypes.data_as(ctypes.POINTER(ct))
+
+
+def host_threads() -> int:
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:  # pragma: no cover
+        return os.cpu_count() or 1
+
+
+# --------------------------------------------------------------------------- k-NN
+def knn(query, ref, k, nthreads: int = 0):
+    """Exact k nearest rows of ``ref`` for every row of ``query``.
+
+    Returns ``(idx int32 [n,k], dist float32 [n,k])``; distance is ``sqrtf(D)``
+    of the float32 squared distance ``D`` that orders the rows (ties by index).
+    """
+    q = np.ascontiguousarray(np.asarray(query), dtype=np.float32)
+    r = np.ascontiguousarray(np.asarray(ref), dtype=np.float32)
+    if q.ndim != 2 or r.ndim != 2 or q.shape[1] != r.shape[1]:
+        raise ValueError("query and ref must be 2-D with the same number of columns")
+    n, d = q.shape
+    m = r.shape[0]
+    idx = np.empty((n, k), dtype=np.int32)
+    d2 = np.empty((n, k), dtype=np.float32)
+    rc = _lib().oracle_knn(_p(q, ctypes.c_float), n, _p(r, ctypes.c_float), m, d, int(k),
+                           _p(idx, ctypes.c_int32), _p(d2, ctypes.c_float), int(nthreads))
+    if rc != 0:
+        raise ValueError("oracle_knn: bad arguments")
+    return idx, np.sqrt(d2, dtype=np.float32)
+
+
+def knn_dist2(query, ref, k, nthreads: int = 0):
+    """As :func:`knn` but returns the ordering key ``D`` (squared distance)."""
+    q = np.ascontiguousarray(np.asarray(query), dtype=np.float32)
+    r = np.ascontiguousarray(np.asarray(ref), dtype=np.float32)
+    n, d = q.shape
+    idx = np.empty((n, k), dtype=np.int32)
+    d2 = np.empty((n, k), dtype=np.float32)
+    _lib().oracle_knn(_p(q, ctypes.c_float), n, _p(r, ctypes.c_float), r.shape[0], d, int(k),
+                      _p(idx, ctypes.c_int32), _p(d2, ctypes.c_float), int(nthreads))
+    return idx, d2
+
+
+class ExactNNDescent:
+    """Exact stand-in with the three members ``find_neighbor`` uses of
+    ``pynndescent.NNDescent`` (call sites ``anchors.py:546-565``): the
+    constructor, ``neighbor_graph`` and ``query``."""
+
+    def __init__(self, data, metric="euclidean", n_neighbors=30, random_state=None,
+                 parallel_batch_queries=False, n_jobs=None, **_ignored):
+        if metric != "euclidean":
+            raise ValueError("only the euclidean metric is restated")
+        self._data = np.ascontiguousarray(np.asarray(data), dtype=np.float32)
+        self.n_neighbors = int(n_neighbors)
+        self._graph = None
+
+    @property
+    def neighbor_graph(self):
+        if self._graph is None:
+            self._graph = knn(self._data, self._data, self.n_neighbors)
+        return self._graph
+
+    def query(self, query_data, k=10, epsilon=0.1):
+        return knn(query_data, self._data, k)
+
+
+def find_neighbor(cc1, cc2, k, random_state=0, n_jobs=-1):
+    """anchors.py:525-566 with the exact index."""
+    index = ExactNNDescent(cc1, metric="euclidean", n_neighbors=k + 1)
+    G11 = index.neighbor_graph[0][:, 1:k + 1]
+    G21 = index.query(cc2, k=k)[0]
+    index = ExactNNDescent(cc2, metric="euclidean", n_neighbors=k + 1)
+    G22 = index.neighbor_graph[0][:, 1:k + 1]
+    G12 = index.query(cc1, k=k)[0]
+    return G11, G12, G21, G22
+
+
+# ------------------------------------------------------------------ MNN / scoring
+def find_mnn_loops(G12, G21, kanchor):
+    """anchors.py:569-572 as plain Python loops (small inputs only)."""
+    anchor = []
+    for i in range(G12.shape[0]):
+        for j in range(kanchor):
+            row = G21[G12[i, j], :kanchor]
+            if any(int(v) == i for v in row):
+                anchor.append([i, G12[i, j]])
+    return np.array(anchor)
+
+
+def find_mnn(G12, G21, kanchor):
+    """anchors.py:569-572; C loop, same row order and the same ``(0,)``-shaped
+    result when no pair is mutual."""
+    G12 = np.asarray(G12)
+    G21 = np.asarray(G21)
+    if kanchor > G12.shape[1] or kanchor > G21.shape[1]:
+        raise IndexError("kanchor exceeds the number of neighbour columns")
+    g12 = np.ascontiguousarray(G12, dtype=np.int32)
+    g21 = np.ascontiguousarray(G21, dtype=np.int32)
+    pairs = np.empty((g12.shape[0] * kanchor, 2), dtype=np.int64)
+    cnt = _lib().oracle_find_mnn(_p(g12, ctypes.c_int32), g12.shape[0], g12.shape[1],
+                                 _p(g21, ctypes.c_int32), g21.shape[0], g21.shape[1],
+                                 int(kanchor), _p(pairs, ctypes.c_int64))
+    if cnt < 0:
+        raise IndexError("neighbour index out of bounds")
+    if cnt == 0:
+        return np.array([])
+    return pairs[:cnt].copy()
+
+
+def min_max(tmp, q_left=1, q_right=90):
+    """anchors.py:575-581."""
+    tmin, tmax = np.percentile(tmp, [q_left, q_right])
+    tmp = (tmp - tmin) / (tmax - tmin)
+    tmp[tmp > 1] = 1
+    tmp[tmp < 0] = 0
+    return tmp
+
+
+def snn_counts(anchor, G11, G12, G21, G22, k_score=30):
+    """The integer list ``tmp`` of anchors.py:660-664."""
+    anchor = np.ascontiguousarray(np.asarray(anchor), dtype=np.int64)
+    if anchor.size == 0:
+        return np.empty(0, dtype=np.int32)
+    tabs = [np.ascontiguousarray(np.asarray(g)[:, :k_score], dtype=np.int32)
+            for g in (G11, G12, G21, G22)]
+    ks = min(t.shape[1] for t in tabs)
+    if any(t.shape[1] != ks for t in tabs):
+        raise ValueError("neighbour tables must share their column count")
+    out = np.empty(anchor.shape[0], dtype=np.int32)
+    rc = _lib().oracle_snn_score(_p(anchor, ctypes.c_int64), anchor.shape[0],
+                                 _p(tabs[0], ctypes.c_int32), _p(tabs[1], ctypes.c_int32),
+                                 _p(tabs[2], ctypes.c_int32), _p(tabs[3], ctypes.c_int32),
+                                 tabs[0].shape[0], tabs[2].shape[0], ks, ks,
+                                 _p(out, ctypes.c_int32))
+    if rc != 0:
+        raise IndexError("anchor index out of bounds")
+    return out
+
+
+def snn_counts_loops(anchor, G11, G12, G21, G22, k_score=30):
+    """anchors.py:660-664 with Python sets (small inputs only)."""
+    return [
+        len(set(G11[x, :k_score]).intersection(G21[y, :k_score]))
+        + len(set(G12[x, :k_score]).intersection(G22[y, :k_score]))
+        for x, y in anchor
+    ]
+
+
+def score_anchor(anchor, G11, G12, G21, G22, k_score=30, Gp1=None, Gp2=None, k_local=50):
+    """anchors.py:631-679 (``k_local`` branch included for completeness)."""
+    tmp = [int(v) for v in snn_counts(anchor, G11, G12, G21, G22, k_score)]
+    anchor_df = pd.DataFrame(anchor, columns=["x1", "x2"])
+    anchor_df["score"] = min_max(tmp)
+    if k_local:
+        share_nn = np.array([len(set(Gp1[i]).intersection(G11[i, :k_local])) for i in range(len(Gp1))])
+        tmp = [share_nn[xx] for xx in anchor_df["x1"].values]
+        anchor_df["score_local1"] = min_max(tmp)
+        share_nn = np.array([len(set(Gp2[i]).intersection(G22[i, :k_local])) for i in range(len(Gp2))])
+        tmp = [share_nn[xx] for xx in anchor_df["x2"].values]
+        anchor_df["score_local2"] = min_max(tmp)
+        anchor_df["score"] = anchor_df["score"] * anchor_df["score_local1"] * anchor_df["score_local2"]
+    return anchor_df
+
+
+# ------------------------------------------------------------ pairwise orchestration
+def l2_normalize_rows(X):
+    """sklearn.preprocessing.normalize(X, axis=1) for dense input
+    (anchors.py:877-878): rows divided by their L2 norm, zero rows kept."""
+    X = np.array(X, dtype=np.float64, copy=True)
+    norms = np.sqrt(np.einsum("ij,ij->i", X, X))
+    norms[norms == 0.0] = 1.0
+    X /= norms[:, np.newaxis]
+    return X
+
+
+def pairwise_anchors(U, V, k_anchor=5, k_score=30, k_local=None, normalize_rows=False):
+    """Steps 3, 4 and 6 of ``_pairwise_find_anchor`` (anchors.py:874-890 for the
+    "cca" branch with ``normalize_rows``; 971-987 for "precomputed"; 1021-1037)."""
+    if normalize_rows:
+        U = l2_normalize_rows(U)
+        V = l2_normalize_rows(V)
+    min_sample = min(U.shape[0], V.shape[0])
+    _k = max(t for t in [k_anchor, k_local, k_score] if t is not None)
+    _k = min(min_sample - 2, _k)
+    G11, G12, G21, G22 = find_neighbor(U, V, k=_k)
+    raw_anchors = find_mnn(G12, G21, k_anchor)
+    anchor_df = score_anchor(raw_anchors, G11, G12, G21, G22, k_score=k_score, k_local=k_local)
+    return anchor_df, (G11, G12, G21, G22), raw_anchors
+
+
+def label_filter(anchor_df, rna_labels, atac_labels, ct_filter=True, threshold=0.2):
+    """scmiac/modeling/scmiac.py:90-99."""
+    anchor_df = anchor_df.copy()
+    anchor_df["x1_ct"] = np.asarray(rna_labels)[anchor_df["x1"].values]
+    anchor_df["x2_ct"] = np.asarray(atac_labels)[anchor_df["x2"].values]
+    anchor_df["is_same"] = anchor_df["x1_ct"].astype(str) == anchor_df["x2_ct"].astype(str)
+    anchor_df = anchor_df[anchor_df["score"] > threshold].reset_index(drop=True)
+    if ct_filter:
+        anchor_df = anchor_df[anchor_df["is_same"]]
+    return anchor_df
