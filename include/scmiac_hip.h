@@ -1,0 +1,161 @@
+/*
+ * libscmiac_hip.so -- C ABI of the MI355X (gfx950) anchor-search kernels.
+ *
+ * Every entry point returns 0 on success and a non-zero status otherwise;
+ * scmiac_last_error() then holds a human-readable reason (thread-local).  All
+ * array arguments are DEVICE pointers owned by the caller; nothing is allocated,
+ * freed or synchronised inside (work is enqueued on `stream`, a hipStream_t
+ * passed as void*; NULL is the default stream).  No C++ types cross the boundary.
+ *
+ * The reference (TianLab-Bioinfo/scMIAC) is pure Python and has no FFI of its
+ * own; each entry point names the reference function whose arithmetic it
+ * replaces (paths relative to the reference checkout).
+ */
+#ifndef SCMIAC_HIP_H
+#define SCMIAC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define SCMIAC_API __attribute__((visibility("default")))
+#else
+#define SCMIAC_API
+#endif
+
+#define SCMIAC_OK 0
+#define SCMIAC_ERR_ARG 1       /* bad argument (shape, NULL pointer, unsupported size) */
+#define SCMIAC_ERR_WORKSPACE 2 /* workspace too small */
+#define SCMIAC_ERR_HIP 3       /* a HIP runtime call failed */
+
+#define SCMIAC_KNN_MAX_K 64   /* neighbours per row one search can return */
+#define SCMIAC_KNN_MAX_D 128  /* feature dimension supported by the fused kernel */
+
+/* Library/ABI version (major*1000 + minor). */
+SCMIAC_API int scmiac_version(void);
+
+/* Message for the last non-zero status returned on this thread. */
+SCMIAC_API const char *scmiac_last_error(void);
+
+/*
+ * Bytes of device scratch scmiac_knn_search needs for an (n x d) query block
+ * against an (m x d) reference block.  `splits` = 0 lets the library choose how
+ * many reference chunks to search independently (more chunks fill the GPU when n
+ * is small); pass the same value to scmiac_knn_search.
+ */
+SCMIAC_API int scmiac_knn_workspace_size(int64_t n, int64_t m, int d, int k, int splits, size_t *bytes);
+
+/*
+ * Exact k nearest reference rows for every query row -- the arithmetic behind
+ *   scmiac/preprocessing/anchors.py:546-565
+ *     pynndescent.NNDescent(ref, metric="euclidean", n_neighbors=k+1).neighbor_graph
+ *     index.query(q, k=k)
+ * (third-party, approximate there; exact here).  Squared distance
+ *   D(a,b) = fmaf chain over (a_i-b_i)^2 in float32, feature index ascending,
+ * rows ordered by (D, reference row number) ascending.
+ *
+ *   q      [n*d]  float32 row-major queries            (device)
+ *   r      [m*d]  float32 row-major references         (device)
+ *   col_offset    added to every reported reference row number (reference block
+ *                 m0..m0+m of a larger set; 0 otherwise)
+ *   merge         0: idx/dist2/lower_bound are outputs only.
+ *                 1: they also hold the result of earlier calls over OTHER
+ *                    reference blocks of the same set; the result is the exact
+ *                    top-k of the union (ring-passed / tiled reference sets).
+ *   idx    [n*k]  int32   neighbour row numbers (+col_offset); -1 past the end
+ *   dist2  [n*k]  float32 D, ascending; +inf past the end
+ *   dist   [n*k]  float32 sqrtf(D), or NULL
+ *   lower_bound [n] float64: every reference row seen so far that is NOT in
+ *                 idx has D >= lower_bound (proved from the fused kernel's
+ *                 rounding-error bound); rows whose k-th D is below it are exact.
+ *   uncertified_rows [n] int32, n_uncertified [1] int32: rows for which that
+ *                 proof failed (distance ties / near-ties at the shortlist edge).
+ *   exact_fallback 1: those rows are re-searched against `r` by direct
+ *                 evaluation before returning, so the result is exact for every
+ *                 row (use 0 only when `r` is one block of several; then call
+ *                 scmiac_knn_exact_rows for each block afterwards).
+ *   1 <= k <= SCMIAC_KNN_MAX_K, 1 <= d <= SCMIAC_KNN_MAX_D, n, m < 2^31.
+ */
+SCMIAC_API int scmiac_knn_search(const float *q, int64_t n, const float *r, int64_t m, int d, int k,
+                      int64_t col_offset, int merge, int splits, int32_t *idx, float *dist2,
+                      float *dist, double *lower_bound, int32_t *uncertified_rows,
+                      int32_t *n_uncertified, int exact_fallback, void *workspace,
+                      size_t workspace_bytes, void *stream);
+
+/*
+ * Direct-evaluation search for a list of query rows: merges the exact top-k of
+ * reference block `r` into idx/dist2 (which must already hold k valid-or-padded
+ * entries per row, e.g. from scmiac_knn_search).  `rows` [*n_rows] int32 and
+ * n_rows [1] int32 live on the device.  Same ordering rule as scmiac_knn_search;
+ * same reference call sites.
+ */
+SCMIAC_API int scmiac_knn_exact_rows(const float *q, int64_t n, const float *r, int64_t m, int d, int k,
+                          int64_t col_offset, const int32_t *rows, const int32_t *n_rows,
+                          int32_t *idx, float *dist2, float *dist, void *stream);
+
+/*
+ * Mutual-nearest-neighbour anchors -- scmiac/preprocessing/anchors.py:569-572
+ *   [[i, G12[i,j]] for i in range(n1) for j in range(ka) if i in G21[G12[i,j], :ka]]
+ *   g12 [n1*ld12], g21 [n2*ld21] int32 row-major neighbour tables
+ *   pairs [n1*ka*2] int64 out, rows in (i, j) order; n_pairs [1] int64 out
+ *   status [1] int32 out: 0, or 1 when an entry of g12 is not a row of g21
+ *   workspace: scmiac_compact_workspace_size(n1*ka) bytes
+ */
+SCMIAC_API int scmiac_find_mnn(const int32_t *g12, int64_t n1, int64_t ld12, const int32_t *g21, int64_t n2,
+                    int64_t ld21, int ka, int64_t *pairs, int64_t *n_pairs, int32_t *status,
+                    void *workspace, size_t workspace_bytes, void *stream);
+
+/* Scratch bytes for the ordered-compaction passes over `n_items` flags. */
+SCMIAC_API int scmiac_compact_workspace_size(int64_t n_items, size_t *bytes);
+
+/*
+ * Shared-neighbour anchor score before normalisation --
+ * scmiac/preprocessing/anchors.py:660-664
+ *   len(set(G11[x,:ks]) & set(G21[y,:ks])) + len(set(G12[x,:ks]) & set(G22[y,:ks]))
+ *   pairs [n_pairs*2] int64, *n_pairs read on the device (n_pairs_max bounds the launch)
+ *   g11,g12 [n1*ld], g21,g22 [n2*ld] int32;  score [n_pairs] int32 out
+ *   hist [2*ks+1] int64 out (may be NULL): histogram of the scores
+ */
+SCMIAC_API int scmiac_snn_score(const int64_t *pairs, const int64_t *n_pairs, int64_t n_pairs_max,
+                     const int32_t *g11, const int32_t *g12, const int32_t *g21,
+                     const int32_t *g22, int64_t n1, int64_t n2, int64_t ld, int ks,
+                     int32_t *score, int64_t *hist, void *stream);
+
+/*
+ * Score normalisation tail and cell-type filter --
+ * scmiac/preprocessing/anchors.py:578-580 (given the two percentiles) and
+ * scmiac/modeling/scmiac.py:91-99
+ *   score = clip((raw - p_lo) / (p_hi - p_lo), 0, 1)           (float64)
+ *   is_same = codes1[x1] == codes2[x2];  keep score > threshold;  then is_same
+ * Outputs are compacted in input order:
+ *   out_pairs [n*2] int64, out_score [n] float64, out_is_same [n] uint8,
+ *   out_index [n] int64 (row label after the score filter's reset_index),
+ *   counts [2] int64: {rows with score > threshold, rows written}
+ *   all_score [n] float64 out (may be NULL): normalised score of every input row
+ *   ct_filter 0 keeps rows whatever is_same says (they are still reported).
+ *   workspace: scmiac_compact_workspace_size(n_pairs_max) bytes
+ */
+SCMIAC_API int scmiac_anchor_filter(const int64_t *pairs, const int64_t *n_pairs, int64_t n_pairs_max,
+                         const int32_t *raw_score, double p_lo, double p_hi, double threshold,
+                         const int32_t *codes1, int64_t n1, const int32_t *codes2, int64_t n2,
+                         int ct_filter, int64_t *out_pairs, double *out_score,
+                         uint8_t *out_is_same, int64_t *out_index, int64_t *counts,
+                         double *all_score, void *workspace, size_t workspace_bytes,
+                         void *stream);
+
+/*
+ * Optional in-library timing of the fused distance + top-k kernel: when enabled,
+ * scmiac_knn_search brackets that kernel's launch with HIP events on `stream`;
+ * scmiac_knn_last_fused_ms waits for them and returns the elapsed milliseconds.
+ */
+SCMIAC_API int scmiac_knn_set_timing(int enabled);
+SCMIAC_API int scmiac_knn_last_fused_ms(float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCMIAC_HIP_H */

@@ -1,0 +1,246 @@
+"""ctypes binding of ``libscmiac_hip.so`` (C ABI in ``include/scmiac_hip.h``).
+
+PyTorch supplies device memory and the stream; every computation on the anchor
+path goes through the HIP kernels.  There is no CPU or eager-PyTorch fallback:
+if the library is missing or no MI355X is visible, the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes
+from pathlib import Path
+
+import torch
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "csrc" / "libscmiac_hip.so"
+
+KNN_MAX_K = 64
+KNN_MAX_D = 128
+
+_lib = None
+
+_c = ctypes
+_vp, _i64, _i32, _sz, _dbl = _c.c_void_p, _c.c_int64, _c.c_int, _c.c_size_t, _c.c_double
+
+_SIGNATURES = {
+    "scmiac_version": ([], _c.c_int),
+    "scmiac_last_error": ([], _c.c_char_p),
+    "scmiac_knn_workspace_size": ([_i64, _i64, _i32, _i32, _i32, _c.POINTER(_sz)], _c.c_int),
+    "scmiac_knn_search": ([_vp, _i64, _vp, _i64, _i32, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp,
+                           _vp, _i32, _vp, _sz, _vp], _c.c_int),
+    "scmiac_knn_exact_rows": ([_vp, _i64, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
+                              _c.c_int),
+    "scmiac_find_mnn": ([_vp, _i64, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _sz, _vp], _c.c_int),
+    "scmiac_compact_workspace_size": ([_i64, _c.POINTER(_sz)], _c.c_int),
+    "scmiac_snn_score": ([_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp],
+                         _c.c_int),
+    "scmiac_anchor_filter": ([_vp, _vp, _i64, _vp, _dbl, _dbl, _dbl, _vp, _i64, _vp, _i64, _i32, _vp, _vp,
+                              _vp, _vp, _vp, _vp, _vp, _sz, _vp], _c.c_int),
+    "scmiac_knn_set_timing": ([_i32], _c.c_int),
+    "scmiac_knn_last_fused_ms": ([_c.POINTER(_c.c_float)], _c.c_int),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+class ScmiacHipError(RuntimeError):
+    pass
+
+
+def load_library():
+    """Load the shared library (no GPU needed for loading itself)."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise ScmiacHipError(
+                f"{LIB_PATH} is missing: build it with `make -C {LIB_PATH.parent}` "
+                "(or `python -c 'import __graft_entry__ as g; g.build()'`); there is no CPU fallback")
+        lib = ctypes.CDLL(str(LIB_PATH))
+        for name, (argtypes, restype) in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.argtypes = argtypes
+            fn.restype = restype
+        _lib = lib
+    return _lib
+
+
+def _check(rc: int):
+    if rc != 0:
+        msg = load_library().scmiac_last_error().decode("utf-8", "replace")
+        raise (ValueError if rc == 1 else ScmiacHipError)(f"libscmiac_hip status {rc}: {msg}")
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise ScmiacHipError("no HIP device visible: the anchor search runs only on the GPU (no CPU fallback)")
+    return load_library()
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev_f32(x, device):
+    t = torch.as_tensor(x)
+    if t.dtype != torch.float32 or t.device != device or not t.is_contiguous():
+        t = t.to(device=device, dtype=torch.float32).contiguous()
+    return t
+
+
+def _dev_i32(x, device):
+    t = torch.as_tensor(x)
+    if t.dtype != torch.int32 or t.device != device or not t.is_contiguous():
+        t = t.to(device=device, dtype=torch.int32).contiguous()
+    return t
+
+
+class KnnState:
+    """Running result of a search over one or more reference blocks."""
+
+    def __init__(self, n, k, device):
+        self.idx = torch.empty((n, k), dtype=torch.int32, device=device)
+        self.dist2 = torch.empty((n, k), dtype=torch.float32, device=device)
+        self.dist = torch.empty((n, k), dtype=torch.float32, device=device)
+        self.lower_bound = torch.empty((n,), dtype=torch.float64, device=device)
+        self.uncertified_rows = torch.empty((max(n, 1),), dtype=torch.int32, device=device)
+        self.n_uncertified = torch.zeros((1,), dtype=torch.int32, device=device)
+        self.blocks = 0
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes, device):
+    """One grow-only scratch tensor per device (the C ABI allocates nothing)."""
+    ws = _ws_cache.get(device)
+    if ws is None or ws.numel() < nbytes:
+        _ws_cache[device] = None
+        ws = torch.empty((int(nbytes),), dtype=torch.uint8, device=device)
+        _ws_cache[device] = ws
+    return ws
+
+
+def knn_search(q, r, k, *, col_offset=0, state=None, splits=0, exact_fallback=True):
+    """Exact k-NN of the rows of ``q`` among the rows of ``r`` (device tensors).
+
+    Returns a :class:`KnnState`; pass it back as ``state`` with another
+    reference block (and that block's ``col_offset``) to extend the search.
+    """
+    lib = require_gpu()
+    device = q.device if isinstance(q, torch.Tensor) and q.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    q = _dev_f32(q, device)
+    r = _dev_f32(r, device)
+    if q.dim() != 2 or r.dim() != 2 or q.shape[1] != r.shape[1]:
+        raise ValueError("q and r must be 2-D with the same number of columns")
+    n, d = q.shape
+    m = r.shape[0]
+    merge = 0 if state is None else 1
+    if state is None:
+        state = KnnState(n, k, device)
+    elif state.idx.shape != (n, k):
+        raise ValueError("state does not match (n, k)")
+    nbytes = ctypes.c_size_t(0)
+    _check(lib.scmiac_knn_workspace_size(n, m, d, k, splits, ctypes.byref(nbytes)))
+    ws = _workspace(nbytes.value, device)
+    with torch.cuda.device(device):
+        _check(lib.scmiac_knn_search(_ptr(q), n, _ptr(r), m, d, k, col_offset, merge, splits, _ptr(state.idx),
+                                     _ptr(state.dist2), _ptr(state.dist), _ptr(state.lower_bound),
+                                     _ptr(state.uncertified_rows), _ptr(state.n_uncertified),
+                                     1 if exact_fallback else 0, _ptr(ws), ws.numel(), _stream()))
+    state.blocks += 1
+    return state
+
+
+def knn_exact_rows(q, r, k, rows, n_rows, state, *, col_offset=0):
+    lib = require_gpu()
+    device = state.idx.device
+    q = _dev_f32(q, device)
+    r = _dev_f32(r, device)
+    with torch.cuda.device(device):
+        _check(lib.scmiac_knn_exact_rows(_ptr(q), q.shape[0], _ptr(r), r.shape[0], q.shape[1], k, col_offset,
+                                         _ptr(rows), _ptr(n_rows), _ptr(state.idx), _ptr(state.dist2),
+                                         _ptr(state.dist), _stream()))
+    return state
+
+
+def find_mnn(g12, g21, ka):
+    """Device MNN search; returns ``(pairs int64 [n1*ka, 2], n_pairs int64 [1], status int32 [1])``."""
+    lib = require_gpu()
+    device = g12.device
+    g12 = _dev_i32(g12, device)
+    g21 = _dev_i32(g21, device)
+    n1, ld12 = g12.shape
+    n2, ld21 = g21.shape
+    pairs = torch.empty((max(n1 * ka, 1), 2), dtype=torch.int64, device=device)
+    n_pairs = torch.zeros((1,), dtype=torch.int64, device=device)
+    status = torch.zeros((1,), dtype=torch.int32, device=device)
+    nbytes = ctypes.c_size_t(0)
+    _check(lib.scmiac_compact_workspace_size(n1 * ka, ctypes.byref(nbytes)))
+    ws = _workspace(nbytes.value, device)
+    with torch.cuda.device(device):
+        _check(lib.scmiac_find_mnn(_ptr(g12), n1, ld12, _ptr(g21), n2, ld21, ka, _ptr(pairs), _ptr(n_pairs),
+                                   _ptr(status), _ptr(ws), ws.numel(), _stream()))
+    return pairs, n_pairs, status
+
+
+def snn_score(pairs, n_pairs, g11, g12, g21, g22, ks, *, n_pairs_max=None, want_hist=False):
+    """Raw shared-neighbour scores (int32 [n_pairs_max]) of the first ``n_pairs`` rows of ``pairs``."""
+    lib = require_gpu()
+    device = pairs.device
+    widths = {int(g.shape[1]) for g in (g11, g12, g21, g22)}
+    if len(widths) != 1:  # differing widths: cut every table to its first ks columns
+        g11, g12, g21, g22 = (g[:, :ks] for g in (g11, g12, g21, g22))
+    tabs = [_dev_i32(g, device) for g in (g11, g12, g21, g22)]
+    ld = tabs[0].shape[1]
+    if ks > ld:
+        raise IndexError("k_score exceeds the number of neighbour columns")
+    if n_pairs_max is None:
+        n_pairs_max = pairs.shape[0]
+    score = torch.empty((max(n_pairs_max, 1),), dtype=torch.int32, device=device)
+    hist = torch.zeros((2 * ks + 1,), dtype=torch.int64, device=device) if want_hist else None
+    with torch.cuda.device(device):
+        _check(lib.scmiac_snn_score(_ptr(pairs), _ptr(n_pairs), n_pairs_max, _ptr(tabs[0]), _ptr(tabs[1]),
+                                    _ptr(tabs[2]), _ptr(tabs[3]), tabs[0].shape[0], tabs[2].shape[0], ld, ks,
+                                    _ptr(score), _ptr(hist), _stream()))
+    return score, hist
+
+
+def anchor_filter(pairs, n_pairs, raw_score, p_lo, p_hi, codes1, codes2, *, threshold=0.2, ct_filter=True,
+                  n_pairs_max=None, want_all_scores=False):
+    """Normalised score + label filter with ordered compaction (device)."""
+    lib = require_gpu()
+    device = pairs.device
+    codes1 = _dev_i32(codes1, device)
+    codes2 = _dev_i32(codes2, device)
+    if n_pairs_max is None:
+        n_pairs_max = pairs.shape[0]
+    cap = max(n_pairs_max, 1)
+    out_pairs = torch.empty((cap, 2), dtype=torch.int64, device=device)
+    out_score = torch.empty((cap,), dtype=torch.float64, device=device)
+    out_same = torch.empty((cap,), dtype=torch.uint8, device=device)
+    out_index = torch.empty((cap,), dtype=torch.int64, device=device)
+    counts = torch.zeros((2,), dtype=torch.int64, device=device)
+    all_score = torch.empty((cap,), dtype=torch.float64, device=device) if want_all_scores else None
+    nbytes = ctypes.c_size_t(0)
+    _check(lib.scmiac_compact_workspace_size(n_pairs_max, ctypes.byref(nbytes)))
+    ws = _workspace(nbytes.value, device)
+    with torch.cuda.device(device):
+        _check(lib.scmiac_anchor_filter(_ptr(pairs), _ptr(n_pairs), n_pairs_max, _ptr(raw_score), float(p_lo),
+                                        float(p_hi), float(threshold), _ptr(codes1), codes1.shape[0],
+                                        _ptr(codes2), codes2.shape[0], 1 if ct_filter else 0, _ptr(out_pairs),
+                                        _ptr(out_score), _ptr(out_same), _ptr(out_index), _ptr(counts),
+                                        _ptr(all_score), _ptr(ws), ws.numel(), _stream()))
+    return out_pairs, out_score, out_same, out_index, counts, all_score
+
+
+def set_timing(enabled: bool):
+    _check(load_library().scmiac_knn_set_timing(1 if enabled else 0))
+
+
+def last_fused_ms() -> float:
+    ms = ctypes.c_float(0.0)
+    _check(load_library().scmiac_knn_last_fused_ms(ctypes.byref(ms)))
+    return float(ms.value)

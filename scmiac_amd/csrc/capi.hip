@@ -1,0 +1,226 @@
+// extern "C" boundary of libscmiac_hip.so (declared in include/scmiac_hip.h).
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/scmiac_hip.h"
+#include "kernels.h"
+
+using namespace scmiac;
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+static int hip_fail(hipError_t e, const char* what) {
+    return fail(SCMIAC_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+#define HIP_TRY(expr, what)                              \
+    do {                                                 \
+        hipError_t _e = (expr);                          \
+        if (_e != hipSuccess) return hip_fail(_e, what); \
+    } while (0)
+
+static inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// workspace carve-up of one search
+struct KnnWs {
+    float* qp;
+    float* rp;
+    float* rnorm;
+    unsigned long long* lists;
+    unsigned* maxnorm;
+    size_t total;
+};
+static KnnWs knn_carve(void* ws, long long n, const KnnGeometry& g) {
+    (void)n;
+    unsigned char* p = static_cast<unsigned char*>(ws);
+    KnnWs w;
+    size_t off = 0;
+    w.qp = reinterpret_cast<float*>(p + off);
+    off += up256(sizeof(float) * (size_t)g.n_pad * g.rowf);
+    w.rp = reinterpret_cast<float*>(p + off);
+    off += up256(sizeof(float) * (size_t)g.m_pad * g.rowf);
+    w.rnorm = reinterpret_cast<float*>(p + off);
+    off += up256(sizeof(float) * (size_t)g.m_pad);
+    w.lists = reinterpret_cast<unsigned long long*>(p + off);
+    off += up256(sizeof(unsigned long long) * (size_t)g.S * g.n_pad * 64);
+    w.maxnorm = reinterpret_cast<unsigned*>(p + off);
+    off += 256;
+    w.total = off;
+    return w;
+}
+
+static int check_knn_args(int64_t n, int64_t m, int d, int k) {
+    if (n < 0 || m < 0) return fail(SCMIAC_ERR_ARG, "negative row count (n=%lld, m=%lld)", (long long)n, (long long)m);
+    if (n >= (1ll << 31) || m >= (1ll << 31)) return fail(SCMIAC_ERR_ARG, "row counts must be below 2^31");
+    if (d < 1 || d > SCMIAC_KNN_MAX_D) return fail(SCMIAC_ERR_ARG, "feature dimension %d outside 1..%d", d, SCMIAC_KNN_MAX_D);
+    if (k < 1 || k > SCMIAC_KNN_MAX_K) return fail(SCMIAC_ERR_ARG, "k=%d outside 1..%d", k, SCMIAC_KNN_MAX_K);
+    return SCMIAC_OK;
+}
+
+static bool g_timing = false;
+static hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
+static bool g_ev_valid = false;
+
+extern "C" {
+
+int scmiac_version(void) { return 1000; }
+
+const char* scmiac_last_error(void) { return g_err; }
+
+int scmiac_knn_workspace_size(int64_t n, int64_t m, int d, int k, int splits, size_t* bytes) {
+    if (!bytes) return fail(SCMIAC_ERR_ARG, "bytes is NULL");
+    int rc = check_knn_args(n, m, d, k);
+    if (rc) return rc;
+    KnnGeometry g = knn_geometry(n, m, d, splits);
+    if (g.D2 < 0) return fail(SCMIAC_ERR_ARG, "unsupported feature dimension %d", d);
+    *bytes = knn_carve(nullptr, n, g).total;
+    return SCMIAC_OK;
+}
+
+int scmiac_knn_search(const float* q, int64_t n, const float* r, int64_t m, int d, int k,
+                      int64_t col_offset, int merge, int splits, int32_t* idx, float* dist2, float* dist,
+                      double* lower_bound, int32_t* uncertified_rows, int32_t* n_uncertified,
+                      int exact_fallback, void* workspace, size_t workspace_bytes, void* stream_) {
+    int rc = check_knn_args(n, m, d, k);
+    if (rc) return rc;
+    if (col_offset < 0 || col_offset + m >= (1ll << 31)) return fail(SCMIAC_ERR_ARG, "col_offset out of range");
+    if (n == 0) return SCMIAC_OK;
+    if (!q || !idx || !dist2 || !lower_bound || !uncertified_rows || !n_uncertified || !workspace)
+        return fail(SCMIAC_ERR_ARG, "NULL device pointer");
+    if (m > 0 && !r) return fail(SCMIAC_ERR_ARG, "NULL reference pointer");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    KnnGeometry g = knn_geometry(n, m, d, splits);
+    if (g.D2 < 0) return fail(SCMIAC_ERR_ARG, "unsupported feature dimension %d", d);
+    KnnWs w = knn_carve(workspace, n, g);
+    if (w.total > workspace_bytes)
+        return fail(SCMIAC_ERR_WORKSPACE, "workspace holds %zu bytes, %zu needed", workspace_bytes, w.total);
+
+    HIP_TRY(hipMemsetAsync(w.maxnorm, 0, 256, stream), "memset maxnorm");
+    HIP_TRY(hipMemsetAsync(n_uncertified, 0, sizeof(int32_t), stream), "memset n_uncertified");
+    HIP_TRY(launch_pack(q, n, d, g, -2.0f, w.qp, nullptr, g.n_pad, w.maxnorm, stream), "pack queries");
+    HIP_TRY(launch_pack(r, m, d, g, 1.0f, w.rp, w.rnorm, g.m_pad, w.maxnorm, stream), "pack references");
+    if (g_timing) {
+        if (!g_ev0) {
+            HIP_TRY(hipEventCreate(&g_ev0), "event create");
+            HIP_TRY(hipEventCreate(&g_ev1), "event create");
+        }
+        HIP_TRY(hipEventRecord(g_ev0, stream), "event record");
+    }
+    HIP_TRY(launch_fused(g, w.qp, w.rp, w.rnorm, w.lists, n, stream), "fused distance + top-k");
+    if (g_timing) {
+        HIP_TRY(hipEventRecord(g_ev1, stream), "event record");
+        g_ev_valid = true;
+    }
+    HIP_TRY(launch_refine(q, r, d, n, g, w.lists, k, col_offset, merge, w.maxnorm, idx, dist2, dist,
+                          lower_bound, uncertified_rows, n_uncertified, stream),
+            "refine");
+    if (exact_fallback)
+        HIP_TRY(launch_exact_rows(q, r, d, n, m, k, col_offset, uncertified_rows, n_uncertified, idx, dist2,
+                                  dist, stream),
+                "exact rows");
+    return SCMIAC_OK;
+}
+
+int scmiac_knn_exact_rows(const float* q, int64_t n, const float* r, int64_t m, int d, int k,
+                          int64_t col_offset, const int32_t* rows, const int32_t* n_rows, int32_t* idx,
+                          float* dist2, float* dist, void* stream_) {
+    int rc = check_knn_args(n, m, d, k);
+    if (rc) return rc;
+    if (n == 0) return SCMIAC_OK;
+    if (!q || !rows || !n_rows || !idx || !dist2) return fail(SCMIAC_ERR_ARG, "NULL device pointer");
+    if (m > 0 && !r) return fail(SCMIAC_ERR_ARG, "NULL reference pointer");
+    HIP_TRY(launch_exact_rows(q, r, d, n, m, k, col_offset, rows, n_rows, idx, dist2, dist,
+                              static_cast<hipStream_t>(stream_)),
+            "exact rows");
+    return SCMIAC_OK;
+}
+
+int scmiac_compact_workspace_size(int64_t n_items, size_t* bytes) {
+    if (!bytes) return fail(SCMIAC_ERR_ARG, "bytes is NULL");
+    if (n_items < 0) return fail(SCMIAC_ERR_ARG, "negative item count");
+    *bytes = compact_workspace_bytes(n_items);
+    return SCMIAC_OK;
+}
+
+int scmiac_find_mnn(const int32_t* g12, int64_t n1, int64_t ld12, const int32_t* g21, int64_t n2,
+                    int64_t ld21, int ka, int64_t* pairs, int64_t* n_pairs, int32_t* status,
+                    void* workspace, size_t workspace_bytes, void* stream_) {
+    if (n1 < 0 || n2 < 0 || ka < 0) return fail(SCMIAC_ERR_ARG, "negative size");
+    if (ka > ld12 || ka > ld21)
+        return fail(SCMIAC_ERR_ARG, "k_anchor=%d exceeds the neighbour columns (%lld, %lld)", ka,
+                    (long long)ld12, (long long)ld21);
+    if (!n_pairs || !status || !workspace) return fail(SCMIAC_ERR_ARG, "NULL device pointer");
+    if (n1 * (int64_t)ka > 0 && (!g12 || !g21 || !pairs)) return fail(SCMIAC_ERR_ARG, "NULL device pointer");
+    size_t need = compact_workspace_bytes(n1 * (int64_t)ka);
+    if (need > workspace_bytes)
+        return fail(SCMIAC_ERR_WORKSPACE, "workspace holds %zu bytes, %zu needed", workspace_bytes, need);
+    HIP_TRY(launch_find_mnn(g12, n1, ld12, g21, n2, ld21, ka, reinterpret_cast<long long*>(pairs),
+                            reinterpret_cast<long long*>(n_pairs), status, workspace,
+                            static_cast<hipStream_t>(stream_)),
+            "find_mnn");
+    return SCMIAC_OK;
+}
+
+int scmiac_snn_score(const int64_t* pairs, const int64_t* n_pairs, int64_t n_pairs_max, const int32_t* g11,
+                     const int32_t* g12, const int32_t* g21, const int32_t* g22, int64_t n1, int64_t n2,
+                     int64_t ld, int ks, int32_t* score, int64_t* hist, void* stream_) {
+    if (n_pairs_max < 0 || n1 < 0 || n2 < 0) return fail(SCMIAC_ERR_ARG, "negative size");
+    if (ks < 1 || ks > ld) return fail(SCMIAC_ERR_ARG, "k_score=%d outside 1..%lld", ks, (long long)ld);
+    if (ks > 2048) return fail(SCMIAC_ERR_ARG, "k_score=%d too large (max 2048)", ks);
+    if (n_pairs_max == 0) return SCMIAC_OK;
+    if (!pairs || !n_pairs || !g11 || !g12 || !g21 || !g22 || !score)
+        return fail(SCMIAC_ERR_ARG, "NULL device pointer");
+    HIP_TRY(launch_snn_score(reinterpret_cast<const long long*>(pairs),
+                             reinterpret_cast<const long long*>(n_pairs), n_pairs_max, g11, g12, g21, g22, n1,
+                             n2, ld, ks, score, reinterpret_cast<long long*>(hist),
+                             static_cast<hipStream_t>(stream_)),
+            "snn_score");
+    return SCMIAC_OK;
+}
+
+int scmiac_anchor_filter(const int64_t* pairs, const int64_t* n_pairs, int64_t n_pairs_max,
+                         const int32_t* raw_score, double p_lo, double p_hi, double threshold,
+                         const int32_t* codes1, int64_t n1, const int32_t* codes2, int64_t n2, int ct_filter,
+                         int64_t* out_pairs, double* out_score, uint8_t* out_is_same, int64_t* out_index,
+                         int64_t* counts, double* all_score, void* workspace, size_t workspace_bytes,
+                         void* stream_) {
+    if (n_pairs_max < 0 || n1 < 0 || n2 < 0) return fail(SCMIAC_ERR_ARG, "negative size");
+    if (!n_pairs || !counts || !workspace) return fail(SCMIAC_ERR_ARG, "NULL device pointer");
+    if (n_pairs_max > 0 && (!pairs || !raw_score || !codes1 || !codes2 || !out_pairs || !out_score ||
+                            !out_is_same || !out_index))
+        return fail(SCMIAC_ERR_ARG, "NULL device pointer");
+    size_t need = compact_workspace_bytes(n_pairs_max);
+    if (need > workspace_bytes)
+        return fail(SCMIAC_ERR_WORKSPACE, "workspace holds %zu bytes, %zu needed", workspace_bytes, need);
+    HIP_TRY(launch_anchor_filter(reinterpret_cast<const long long*>(pairs),
+                                 reinterpret_cast<const long long*>(n_pairs), n_pairs_max, raw_score, p_lo,
+                                 p_hi, threshold, codes1, n1, codes2, n2, ct_filter,
+                                 reinterpret_cast<long long*>(out_pairs), out_score, out_is_same,
+                                 reinterpret_cast<long long*>(out_index), reinterpret_cast<long long*>(counts),
+                                 all_score, workspace, static_cast<hipStream_t>(stream_)),
+            "anchor_filter");
+    return SCMIAC_OK;
+}
+
+int scmiac_knn_set_timing(int enabled) {
+    g_timing = enabled != 0;
+    g_ev_valid = false;
+    return SCMIAC_OK;
+}
+
+int scmiac_knn_last_fused_ms(float* ms) {
+    if (!ms) return fail(SCMIAC_ERR_ARG, "ms is NULL");
+    if (!g_ev_valid) return fail(SCMIAC_ERR_ARG, "no timed search has run");
+    HIP_TRY(hipEventSynchronize(g_ev1), "event synchronize");
+    HIP_TRY(hipEventElapsedTime(ms, g_ev0, g_ev1), "event elapsed");
+    return SCMIAC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,58 @@
+// Internal declarations shared by the kernel translation units and the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#define SCMIAC_KNN_MAX_K_INTERNAL 64
+#define SCMIAC_KNN_MAX_D_INTERNAL 128
+
+namespace scmiac {
+
+// Shapes derived from (n, m, d, splits): padded row counts, packed row length and
+// how the reference rows are cut into independently searched chunks.
+struct KnnGeometry {
+    int D2;                // MFMA K steps per tile (two features per step)
+    int D2P;               // D2 rounded up to a multiple of 4
+    int rowf;              // floats per packed row (2 * D2P)
+    int RT;                // reference rows per LDS stage
+    int qpb;               // queries per block
+    int nqb;               // query blocks
+    int S;                 // reference chunks searched independently
+    long long n_pad;       // queries padded to a multiple of qpb
+    long long chunk_rows;  // rows per chunk (multiple of RT)
+    long long m_pad;       // S * chunk_rows
+};
+
+int knn_pick_d2(int d);
+KnnGeometry knn_geometry(long long n, long long m, int d, int splits);
+
+hipError_t launch_pack(const float* X, long long n, int d, const KnnGeometry& g, float scale, float* Xp,
+                       float* norms, long long n_pad, unsigned* maxnorm_bits, hipStream_t stream);
+hipError_t launch_fused(const KnnGeometry& g, const float* Qp, const float* Rp, const float* rnorm,
+                        unsigned long long* lists, long long n, hipStream_t stream);
+hipError_t launch_refine(const float* Q, const float* R, int d, long long n, const KnnGeometry& g,
+                         const unsigned long long* lists, int k, long long col_offset, int merge,
+                         const unsigned* maxnorm_bits, int* idx, float* d2, float* dist, double* lb,
+                         int* fail_rows, int* n_fail, hipStream_t stream);
+hipError_t launch_exact_rows(const float* Q, const float* R, int d, long long n, long long m, int k,
+                             long long col_offset, const int* rows, const int* n_rows, int* idx,
+                             float* d2, float* dist, hipStream_t stream);
+
+// graph kernels (mutual nearest neighbours, shared-neighbour score, label filter)
+size_t compact_workspace_bytes(long long n_items);
+hipError_t launch_find_mnn(const int* g12, long long n1, long long ld12, const int* g21, long long n2,
+                           long long ld21, int ka, long long* pairs, long long* n_pairs, int* status,
+                           void* ws, hipStream_t stream);
+hipError_t launch_snn_score(const long long* pairs, const long long* n_pairs, long long n_pairs_max,
+                            const int* g11, const int* g12, const int* g21, const int* g22,
+                            long long n1, long long n2, long long ld, int ks, int* score,
+                            long long* hist, hipStream_t stream);
+hipError_t launch_anchor_filter(const long long* pairs, const long long* n_pairs, long long n_pairs_max,
+                                const int* raw, double p_lo, double p_hi, double thr, const int* codes1,
+                                long long n1, const int* codes2, long long n2, int ct_filter,
+                                long long* out_pairs, double* out_score, unsigned char* out_same,
+                                long long* out_index, long long* counts, double* all_score, void* ws,
+                                hipStream_t stream);
+
+}  // namespace scmiac

@@ -1,0 +1,616 @@
+// Fused pairwise-distance + top-k search for gfx950 (MI355X), and the exact
+// refine / direct-evaluation kernels that make its result bit-identical to a
+// float32 direct-difference search.
+//
+// Pipeline of one scmiac_knn_search call (all on one stream, no host sync):
+//   pack_rows      Q, R  -> MFMA-friendly padded copies, |r|^2, max |r|^2
+//   fused_knn      for every query the 64 references with the smallest
+//                  s(q,r) = |r|^2 - 2 q.r   (fp32 MFMA 32x32x2, refs staged in LDS,
+//                  running threshold in a register, candidate buffers in LDS,
+//                  wave-wide bitonic merges) -- the N x M matrix never leaves the CU
+//   refine         exact D(q,r) for the 64*S shortlisted references, (D, index) sort,
+//                  top-k, and a rounding-error certificate that nothing outside the
+//                  shortlist can belong to the top-k
+//   exact_rows     rows whose certificate failed are searched by direct evaluation
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+
+namespace scmiac {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned long long u64;
+
+static constexpr u64 KEY_SENTINEL = 0xffffffffffffffffull;  // sorts after every real key
+// orderable(+inf) in the high word, 0xffffffff index: "no candidate" in the shortlist
+static constexpr u64 LIST_SENTINEL = 0xff800000ffffffffull;
+
+__device__ __forceinline__ unsigned f2ord(float f) {
+    unsigned u = __float_as_uint(f);
+    return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned o) {
+    unsigned u = (o & 0x80000000u) ? (o ^ 0x80000000u) : ~o;
+    return __uint_as_float(u);
+}
+__device__ __forceinline__ u64 umin64(u64 a, u64 b) { return a < b ? a : b; }
+__device__ __forceinline__ u64 umax64(u64 a, u64 b) { return a < b ? b : a; }
+
+// Bitonic sort of one key per lane, ascending across the wave.  WIDTH = 32 sorts
+// lanes 0..31 ascending (and 32..63 descending); WIDTH = 64 sorts all 64 lanes.
+template <int WIDTH>
+__device__ __forceinline__ u64 wave_sort(u64 key, int lane) {
+#pragma unroll
+    for (int k = 2; k <= WIDTH; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            u64 other = __shfl_xor(key, j);
+            bool up = (lane & k) == 0;
+            bool low = (lane & j) == 0;
+            key = (up == low) ? umin64(key, other) : umax64(key, other);
+        }
+    }
+    return key;
+}
+// A bitonic sequence across the 64 lanes -> ascending.
+__device__ __forceinline__ u64 wave_merge(u64 key, int lane) {
+#pragma unroll
+    for (int j = 32; j > 0; j >>= 1) {
+        u64 other = __shfl_xor(key, j);
+        key = ((lane & j) == 0) ? umin64(key, other) : umax64(key, other);
+    }
+    return key;
+}
+
+// --------------------------------------------------------------------------------
+// pack_rows: X[n][d] -> Xp[n_pad][2*D2P] with lane-half-major features
+//   Xp[row][h*D2P + s] = scale * X[row][h*D2 + s]   (0 where h*D2+s >= d or s >= D2)
+// so that lane half h of an MFMA 32x32x2 step s reads feature (h, s) with one aligned
+// 16-byte LDS read per four steps.  norms[row] = fmaf chain of x_i^2 (feature order),
+// +inf on the padding rows (they can then never be candidates).
+// --------------------------------------------------------------------------------
+__global__ void pack_rows_kernel(const float* __restrict__ X, long long n, int d, int D2, int D2P,
+                                 float scale, float* __restrict__ Xp, float* __restrict__ norms,
+                                 long long n_pad, unsigned* __restrict__ maxnorm_bits) {
+    long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_pad) return;
+    const int rowf = 2 * D2P;
+    float* dst = Xp + row * rowf;
+    if (row >= n) {
+        for (int c = 0; c < rowf; ++c) dst[c] = 0.0f;
+        if (norms) norms[row] = __builtin_inff();
+        return;
+    }
+    const float* src = X + row * d;
+    float acc = 0.0f;
+    for (int h = 0; h < 2; ++h) {
+        for (int s = 0; s < D2P; ++s) {
+            int f = h * D2 + s;
+            float v = (s < D2 && f < d) ? src[f] : 0.0f;
+            dst[h * D2P + s] = v * scale;
+        }
+    }
+    for (int i = 0; i < d; ++i) acc = __fmaf_rn(src[i], src[i], acc);
+    if (norms) {
+        norms[row] = acc;
+        atomicMax(maxnorm_bits, __float_as_uint(acc));  // acc >= 0: bit order == value order
+    }
+}
+
+// --------------------------------------------------------------------------------
+// fused_knn
+//   block = NW waves, each wave owns 32 queries (MFMA B operand, columns of the
+//   32x32 result tile) for the whole pass; all waves share the reference stage in LDS
+//   (MFMA A operand, rows).  Lane l: query j = l & 31, reference rows
+//   (r & 3) + 8 (r >> 2) + 4 (l >> 5) of the tile in accumulator register r.
+// --------------------------------------------------------------------------------
+template <int D2>
+struct FusedCfg {
+    static constexpr int D2P = (D2 + 3) & ~3;
+    static constexpr int ROWF = 2 * D2P;  // floats per packed row
+    // LDS row stride: an odd number of 16-byte slots -> conflict-free ds_read_b128
+    static constexpr int LS = ROWF + (((ROWF / 4) % 2 == 0) ? 4 : 0);
+    static constexpr int RT = (D2 <= 32) ? 128 : 64;  // reference rows per LDS stage
+    static constexpr int NW = 8;                       // waves per block
+    static constexpr int PCAP = 32;                    // pending candidates per query
+    static constexpr int QPB = NW * 32;                // queries per block
+    static constexpr size_t lds_bytes() {
+        return sizeof(float) * (2 * RT * LS + 2 * RT) + sizeof(uint2) * (NW * 32 * PCAP) +
+               sizeof(unsigned) * (NW * 32);
+    }
+};
+
+// Merge query q's pending candidates into its 64-entry shortlist (global memory),
+// all 64 lanes cooperating.  Returns the new threshold (score of the 64th entry).
+__device__ __forceinline__ float flush_query(unsigned c, const uint2* pend_q, u64* list_q,
+                                             bool inited, int lane) {
+    u64 key = LIST_SENTINEL;
+    if ((unsigned)lane < c) {
+        uint2 e = pend_q[lane];
+        key = ((u64)f2ord(__uint_as_float(e.x)) << 32) | (u64)e.y;
+    }
+    key = wave_sort<32>(key, lane);  // lanes 0..31 ascending, 32..63 all sentinel
+    u64 old = LIST_SENTINEL;
+    if (inited)  // written earlier by this same wave: read it back from L2, not a stale L1 line
+        old = __hip_atomic_load(list_q + (63 - lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    key = umin64(key, old);  // the 64 smallest of the union, as a bitonic sequence
+    key = wave_merge(key, lane);
+    list_q[lane] = key;
+    unsigned top = __builtin_amdgcn_readlane((unsigned)(key >> 32), 63);
+    return ord2f(top);
+}
+
+template <int D2>
+__global__ __launch_bounds__(FusedCfg<D2>::NW * 64, 2) void fused_knn_kernel(
+    const float* __restrict__ Qp,     // [n_pad][ROWF], already scaled by -2
+    const float* __restrict__ Rp,     // [m_pad][ROWF]
+    const float* __restrict__ rnorm,  // [m_pad]
+    u64* __restrict__ lists,          // [S][n_pad][64]
+    long long n, long long n_pad, int nqb, long long chunk_rows) {
+    using C = FusedCfg<D2>;
+    constexpr int D2P = C::D2P, ROWF = C::ROWF, LS = C::LS, RT = C::RT, NW = C::NW;
+    constexpr int PCAP = C::PCAP, NT = NW * 64, NSUB = RT / 32;
+    constexpr int F4_ROW = ROWF / 4;
+    constexpr int F4_STAGE = RT * F4_ROW;
+    constexpr int LD_ITERS = (F4_STAGE + NT - 1) / NT;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* tile = reinterpret_cast<float*>(smem);           // [2][RT*LS]
+    float* tnorm = tile + 2 * RT * LS;                      // [2][RT]
+    uint2* pend = reinterpret_cast<uint2*>(tnorm + 2 * RT);  // [NW][32][PCAP]
+    unsigned* cnt = reinterpret_cast<unsigned*>(pend + NW * 32 * PCAP);  // [NW][32]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, hh = lane >> 5;
+    const int split = blockIdx.x / nqb, qb = blockIdx.x % nqb;
+    const long long q0 = (long long)qb * C::QPB + wave * 32;  // first query of this wave
+    const long long r_begin = (long long)split * chunk_rows;
+    const int T = (int)(chunk_rows / RT);
+
+    uint2* pend_w = pend + wave * 32 * PCAP;
+    unsigned* cnt_w = cnt + wave * 32;
+    u64* lists_w = lists + ((long long)split * n_pad + q0) * 64;
+
+    // B operand: this lane's query features, one register per MFMA step
+    float b[D2P];
+    {
+        const float4* qp4 = reinterpret_cast<const float4*>(Qp + (q0 + j) * ROWF + hh * D2P);
+#pragma unroll
+        for (int c = 0; c < D2P / 4; ++c) {
+            float4 v = qp4[c];
+            b[4 * c + 0] = v.x; b[4 * c + 1] = v.y; b[4 * c + 2] = v.z; b[4 * c + 3] = v.w;
+        }
+    }
+    // running threshold: score of the 64th best reference so far; padding queries take nothing
+    float tau = (q0 + j < n) ? __builtin_inff() : -__builtin_inff();
+    if (lane < 32) cnt_w[lane] = 0u;
+    unsigned inited = 0u;  // bit q: query q's shortlist exists in global memory (wave-uniform)
+
+    // global -> register -> LDS staging of the next reference stage
+    float4 stg[LD_ITERS];
+    float4 stgn = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < LD_ITERS; ++i) stg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#define SCMIAC_ISSUE(T_)                                                                            \
+    do {                                                                                            \
+        const float4* src_ =                                                                        \
+            reinterpret_cast<const float4*>(Rp + (r_begin + (long long)(T_) * RT) * ROWF);          \
+        _Pragma("unroll") for (int i = 0; i < LD_ITERS; ++i) {                                      \
+            int e = tid + i * NT;                                                                   \
+            if (e < F4_STAGE) stg[i] = src_[e];                                                     \
+        }                                                                                           \
+        if (tid < RT / 4)                                                                           \
+            stgn = reinterpret_cast<const float4*>(rnorm + r_begin + (long long)(T_) * RT)[tid];    \
+    } while (0)
+#define SCMIAC_COMMIT(BUF_)                                                                         \
+    do {                                                                                            \
+        float* tb_ = tile + (BUF_) * RT * LS;                                                       \
+        _Pragma("unroll") for (int i = 0; i < LD_ITERS; ++i) {                                      \
+            int e = tid + i * NT;                                                                   \
+            if (e < F4_STAGE) {                                                                     \
+                int row = e / F4_ROW, c4 = e - row * F4_ROW;                                        \
+                *reinterpret_cast<float4*>(tb_ + row * LS + c4 * 4) = stg[i];                       \
+            }                                                                                       \
+        }                                                                                           \
+        if (tid < RT / 4) reinterpret_cast<float4*>(tnorm + (BUF_) * RT)[tid] = stgn;               \
+    } while (0)
+
+    // flush every query of this wave whose pending count is >= min_cnt (or, at the end,
+    // that has no shortlist in memory yet)
+    auto flush_full = [&](unsigned min_cnt, bool force_uninit) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        unsigned c = cnt_w[j];
+        bool need = (c >= min_cnt) || (force_uninit && !((inited >> j) & 1u) && (q0 + j < n));
+        u64 mask = __ballot(need) & 0xffffffffull;
+        while (mask) {
+            int q = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            unsigned cq = __builtin_amdgcn_readlane(c, q);
+            cq = cq > (unsigned)PCAP ? (unsigned)PCAP : cq;
+            float nt = flush_query(cq, pend_w + q * PCAP, lists_w + (long long)q * 64,
+                                   (inited >> q) & 1u, lane);
+            inited |= 1u << q;
+            if (j == q) tau = nt;
+            if (lane == 0) cnt_w[q] = 0u;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    };
+
+    if (T > 0) {
+        SCMIAC_ISSUE(0);
+        SCMIAC_COMMIT(0);
+    }
+    __syncthreads();
+
+    for (int t = 0; t < T; ++t) {
+        if (t + 1 < T) SCMIAC_ISSUE(t + 1);
+        const float* tb = tile + (t & 1) * RT * LS;
+        const float* nb = tnorm + (t & 1) * RT;
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) {
+            // A operand: reference row (sub*32 + j), this lane half's features
+            float a[D2P];
+            const float4* ap = reinterpret_cast<const float4*>(tb + (sub * 32 + j) * LS + hh * D2P);
+#pragma unroll
+            for (int c = 0; c < D2P / 4; ++c) {
+                float4 v = ap[c];
+                a[4 * c + 0] = v.x; a[4 * c + 1] = v.y; a[4 * c + 2] = v.z; a[4 * c + 3] = v.w;
+            }
+            // accumulator starts at |r|^2 of the row each register holds
+            f32x16 acc;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 nv = *reinterpret_cast<const float4*>(nb + sub * 32 + 8 * g + 4 * hh);
+                acc[4 * g + 0] = nv.x; acc[4 * g + 1] = nv.y; acc[4 * g + 2] = nv.z; acc[4 * g + 3] = nv.w;
+            }
+#pragma unroll
+            for (int s = 0; s < D2; ++s)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+
+            // ---- selection: one compare per 16 pairs on the fast path ----------
+            float mn = fminf(fminf(acc[0], acc[1]), acc[2]);
+#pragma unroll
+            for (int r = 3; r < 15; r += 2) mn = fminf(fminf(mn, acc[r]), acc[r + 1]);
+            mn = fminf(mn, acc[15]);
+            if (__any(mn < tau)) {
+                const unsigned ref0 = (unsigned)(r_begin + (long long)t * RT + sub * 32 + 4 * hh);
+                unsigned fail = 0u;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (acc[r] < tau) {
+                        unsigned slot = atomicAdd(&cnt_w[j], 1u);
+                        if (slot < (unsigned)PCAP)
+                            pend_w[j * PCAP + slot] =
+                                make_uint2(__float_as_uint(acc[r]), ref0 + (r & 3) + 8 * (r >> 2));
+                        else
+                            fail |= 1u << r;
+                    }
+                }
+                while (__any(fail != 0u)) {  // some query's buffer overflowed: merge, retry
+                    flush_full((unsigned)PCAP, false);
+                    unsigned f2 = 0u;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        if (((fail >> r) & 1u) && acc[r] < tau) {
+                            unsigned slot = atomicAdd(&cnt_w[j], 1u);
+                            if (slot < (unsigned)PCAP)
+                                pend_w[j * PCAP + slot] =
+                                    make_uint2(__float_as_uint(acc[r]), ref0 + (r & 3) + 8 * (r >> 2));
+                            else
+                                f2 |= 1u << r;
+                        }
+                    }
+                    fail = f2;
+                }
+            }
+        }
+        if (t + 1 < T) SCMIAC_COMMIT((t + 1) & 1);
+        __syncthreads();
+    }
+    flush_full(1u, true);
+#undef SCMIAC_ISSUE
+#undef SCMIAC_COMMIT
+}
+
+// --------------------------------------------------------------------------------
+// refine: one wave per query.  Exact D for the shortlisted references (oracle
+// arithmetic: t = q_i - r_i; acc = fmaf(t, t, acc), feature order), (D, index) sort,
+// top-k, certificate.
+// --------------------------------------------------------------------------------
+__device__ __forceinline__ float exact_dist2(const float* __restrict__ a, const float* __restrict__ b, int d) {
+    float acc = 0.0f;
+    for (int i = 0; i < d; ++i) {
+        float t = __fsub_rn(a[i], b[i]);
+        acc = __fmaf_rn(t, t, acc);
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void refine_kernel(
+    const float* __restrict__ Q, const float* __restrict__ R, int d, long long n, long long n_pad,
+    const u64* __restrict__ lists, int S, int k, long long col_offset, int merge,
+    double err_abs_coef,  // 2*G: |s + |q|^2 - T| <= err_abs_coef * (|r|^2 + |q|^2)
+    double rel_keep,      // 1 - gamma: D >= T * rel_keep
+    const unsigned* __restrict__ maxnorm_bits, int* __restrict__ out_idx,
+    float* __restrict__ out_d2, float* __restrict__ out_dist, double* __restrict__ lower_bound,
+    int* __restrict__ fail_rows, int* __restrict__ n_fail) {
+    const int lane = threadIdx.x & 63;
+    const long long q = (long long)blockIdx.x * (blockDim.x >> 6) +
+                        __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (q >= n) return;
+    const float* qrow = Q + q * d;
+
+    double qn = 0.0;
+    for (int i = 0; i < d; ++i) qn += (double)qrow[i] * (double)qrow[i];
+    const double rmax2 = (double)__uint_as_float(*maxnorm_bits) * (1.0 + 1e-5);
+
+    u64 best = KEY_SENTINEL;
+    double lb = __builtin_inf();
+    if (merge) {
+        if (lane < k) {
+            int pi = out_idx[q * k + lane];
+            if (pi >= 0) best = ((u64)__float_as_uint(out_d2[q * k + lane]) << 32) | (u64)(unsigned)pi;
+        }
+        lb = lower_bound[q];
+    }
+    for (int s = 0; s < S; ++s) {
+        u64 e = lists[((long long)s * n_pad + q) * 64 + lane];
+        unsigned ridx = (unsigned)e;
+        float tau_s = ord2f(__builtin_amdgcn_readlane((unsigned)(e >> 32), 63));
+        u64 key = KEY_SENTINEL;
+        if (ridx != 0xffffffffu) {
+            float D = exact_dist2(qrow, R + (long long)ridx * d, d);
+            key = ((u64)__float_as_uint(D) << 32) | (u64)(unsigned)(ridx + col_offset);
+        }
+        key = wave_sort<64>(key, lane);
+        u64 rev = __shfl(key, 63 - lane);
+        best = wave_merge(umin64(best, rev), lane);
+        if (tau_s < __builtin_inff()) {
+            double lbs = ((double)tau_s + qn - err_abs_coef * (rmax2 + qn)) * rel_keep;
+            lb = lbs < lb ? lbs : lb;
+        }
+    }
+    // k-th smallest exact key (sentinel when fewer than k candidates exist)
+    unsigned kth_hi = __builtin_amdgcn_readlane((unsigned)(best >> 32), k - 1);
+    unsigned kth_lo = __builtin_amdgcn_readlane((unsigned)best, k - 1);
+    const bool have_k = !(kth_hi == 0xffffffffu && kth_lo == 0xffffffffu);
+    if (lane < k) {
+        bool valid = best != KEY_SENTINEL;
+        float D = __uint_as_float((unsigned)(best >> 32));
+        out_idx[q * k + lane] = valid ? (int)(unsigned)best : -1;
+        out_d2[q * k + lane] = valid ? D : __builtin_inff();
+        if (out_dist) out_dist[q * k + lane] = valid ? __fsqrt_rn(D) : __builtin_inff();
+    }
+    if (lane == 0) {
+        lower_bound[q] = lb;
+        bool certified;
+        if (lb == __builtin_inf()) certified = true;  // every reference seen so far is shortlisted
+        else certified = have_k && ((double)__uint_as_float(kth_hi) < lb);
+        if (!certified) {
+            int p = atomicAdd(n_fail, 1);
+            fail_rows[p] = (int)q;
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------
+// exact_rows: direct evaluation against every reference row for the listed queries;
+// merges into idx/dist2 (top-k of the union).  One 256-thread block per listed row.
+// --------------------------------------------------------------------------------
+static constexpr int EX_CAP = 2048;
+static constexpr int EX_NT = 256;
+
+__device__ void block_bitonic_sort(u64* v, int n_pow2, int tid) {
+    for (int k = 2; k <= n_pow2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < n_pow2; i += EX_NT) {
+                int p = i ^ j;
+                if (p > i) {
+                    bool up = (i & k) == 0;
+                    u64 a = v[i], b = v[p];
+                    if ((a > b) == up) { v[i] = b; v[p] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(EX_NT) void exact_rows_kernel(
+    const float* __restrict__ Q, const float* __restrict__ R, int d, long long m, int k,
+    long long col_offset, const int* __restrict__ rows, const int* __restrict__ n_rows,
+    int* __restrict__ idx_io, float* __restrict__ d2_io, float* __restrict__ dist_out) {
+    __shared__ u64 cand[EX_CAP];
+    __shared__ u64 prior[SCMIAC_KNN_MAX_K_INTERNAL];
+    __shared__ float qs[SCMIAC_KNN_MAX_D_INTERNAL];
+    __shared__ unsigned cnt;
+    __shared__ u64 thr;
+    const int tid = threadIdx.x;
+    const int total = *n_rows;
+    for (int f = blockIdx.x; f < total; f += gridDim.x) {
+        const long long q = rows[f];
+        __syncthreads();
+        for (int i = tid; i < d; i += EX_NT) qs[i] = Q[q * d + i];
+        if (tid < k) {
+            int pi = idx_io[q * k + tid];
+            u64 key = pi >= 0 ? (((u64)__float_as_uint(d2_io[q * k + tid]) << 32) | (u64)(unsigned)pi)
+                              : KEY_SENTINEL;
+            prior[tid] = key;
+            cand[tid] = key;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int nv = 0;
+            while (nv < k && prior[nv] != KEY_SENTINEL) ++nv;
+            // prior rows are sorted ascending: compact form, valid entries first
+            cnt = (unsigned)nv;
+            thr = (nv == k) ? prior[k - 1] : (KEY_SENTINEL - 1);
+        }
+        __syncthreads();
+        for (long long base = 0; base < m; base += EX_NT) {
+            long long x = base + tid;
+            if (x < m) {
+                float D = exact_dist2(qs, R + x * d, d);
+                u64 key = ((u64)__float_as_uint(D) << 32) | (u64)(unsigned)(x + col_offset);
+                if (key <= thr) {
+                    bool dup = false;
+                    for (int p = 0; p < k; ++p) dup |= (prior[p] == key);
+                    if (!dup) {
+                        unsigned slot = atomicAdd(&cnt, 1u);
+                        cand[slot] = key;  // slot < EX_CAP: compaction below keeps EX_NT free
+                    }
+                }
+            }
+            __syncthreads();
+            const unsigned c = cnt;  // every thread reads the same value ...
+            __syncthreads();         // ... before any thread of the next round can add to it
+            if (c > (unsigned)(EX_CAP - EX_NT)) {
+                for (int i = c + tid; i < EX_CAP; i += EX_NT) cand[i] = KEY_SENTINEL;
+                __syncthreads();
+                block_bitonic_sort(cand, EX_CAP, tid);
+                if (tid == 0) {
+                    cnt = c < (unsigned)k ? c : (unsigned)k;
+                    if (c >= (unsigned)k) thr = cand[k - 1];
+                }
+                __syncthreads();
+            }
+        }
+        {
+            unsigned c = cnt;
+            int np2 = 64;
+            while (np2 < (int)c) np2 <<= 1;
+            for (int i = c + tid; i < np2; i += EX_NT) cand[i] = KEY_SENTINEL;
+            __syncthreads();
+            block_bitonic_sort(cand, np2, tid);
+            if (tid < k) {
+                u64 key = (tid < (int)c) ? cand[tid] : KEY_SENTINEL;
+                bool valid = key != KEY_SENTINEL;
+                float D = __uint_as_float((unsigned)(key >> 32));
+                idx_io[q * k + tid] = valid ? (int)(unsigned)key : -1;
+                d2_io[q * k + tid] = valid ? D : __builtin_inff();
+                if (dist_out) dist_out[q * k + tid] = valid ? __fsqrt_rn(D) : __builtin_inff();
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------
+// host-side launchers
+// --------------------------------------------------------------------------------
+static const int kD2Sizes[] = {8, 15, 16, 20, 25, 32, 40, 50, 64};
+
+int knn_pick_d2(int d) {
+    int need = (d + 1) / 2;
+    for (int v : kD2Sizes)
+        if (v >= need) return v;
+    return -1;
+}
+
+template <int D2>
+static hipError_t launch_fused_t(const float* Qp, const float* Rp, const float* rnorm, u64* lists,
+                                 long long n, long long n_pad, int nqb, int S, long long chunk_rows,
+                                 hipStream_t stream) {
+    using C = FusedCfg<D2>;
+    size_t lds = C::lds_bytes();
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_knn_kernel<D2>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    dim3 grid((unsigned)(nqb * S)), block(C::NW * 64);
+    hipLaunchKernelGGL(fused_knn_kernel<D2>, grid, block, lds, stream, Qp, Rp, rnorm, lists, n, n_pad,
+                       nqb, chunk_rows);
+    return hipGetLastError();
+}
+
+KnnGeometry knn_geometry(long long n, long long m, int d, int splits) {
+    KnnGeometry g{};
+    g.D2 = knn_pick_d2(d);
+    if (g.D2 < 0) return g;
+    g.D2P = (g.D2 + 3) & ~3;
+    g.rowf = 2 * g.D2P;
+    g.RT = (g.D2 <= 32) ? 128 : 64;
+    g.qpb = 256;
+    g.n_pad = ((n + g.qpb - 1) / g.qpb) * g.qpb;
+    g.nqb = (int)(g.n_pad / g.qpb);
+    int S = splits;
+    if (S <= 0) {
+        // enough (query block, reference chunk) units to fill 256 CUs a few times over,
+        // but chunks long enough that the per-chunk shortlist warm-up stays small
+        long long want = (1024 + g.nqb - 1) / g.nqb;
+        long long cap = m / 16384;
+        if (cap < 1) cap = 1;
+        S = (int)(want < cap ? want : cap);
+        if (S > 64) S = 64;
+        if (S < 1) S = 1;
+    }
+    long long per = (m + S - 1) / S;
+    g.chunk_rows = ((per + g.RT - 1) / g.RT) * g.RT;
+    if (g.chunk_rows == 0) g.chunk_rows = g.RT;
+    g.S = (int)((m + g.chunk_rows - 1) / g.chunk_rows);
+    if (g.S < 1) g.S = 1;
+    g.m_pad = (long long)g.S * g.chunk_rows;
+    return g;
+}
+
+hipError_t launch_pack(const float* X, long long n, int d, const KnnGeometry& g, float scale, float* Xp,
+                       float* norms, long long n_pad, unsigned* maxnorm_bits, hipStream_t stream) {
+    dim3 block(256), grid((unsigned)((n_pad + 255) / 256));
+    hipLaunchKernelGGL(pack_rows_kernel, grid, block, 0, stream, X, n, d, g.D2, g.D2P, scale, Xp, norms,
+                       n_pad, maxnorm_bits);
+    return hipGetLastError();
+}
+
+hipError_t launch_fused(const KnnGeometry& g, const float* Qp, const float* Rp, const float* rnorm,
+                        unsigned long long* lists, long long n, hipStream_t stream) {
+#define SCMIAC_FUSED_CASE(V)                                                                  \
+    case V:                                                                                   \
+        return launch_fused_t<V>(Qp, Rp, rnorm, lists, n, g.n_pad, g.nqb, g.S, g.chunk_rows, stream);
+    switch (g.D2) {
+        SCMIAC_FUSED_CASE(8)
+        SCMIAC_FUSED_CASE(15)
+        SCMIAC_FUSED_CASE(16)
+        SCMIAC_FUSED_CASE(20)
+        SCMIAC_FUSED_CASE(25)
+        SCMIAC_FUSED_CASE(32)
+        SCMIAC_FUSED_CASE(40)
+        SCMIAC_FUSED_CASE(50)
+        SCMIAC_FUSED_CASE(64)
+        default:
+            return hipErrorInvalidValue;
+    }
+#undef SCMIAC_FUSED_CASE
+}
+
+hipError_t launch_refine(const float* Q, const float* R, int d, long long n, const KnnGeometry& g,
+                         const unsigned long long* lists, int k, long long col_offset, int merge,
+                         const unsigned* maxnorm_bits, int* idx, float* d2, float* dist, double* lb,
+                         int* fail_rows, int* n_fail, hipStream_t stream) {
+    // rounding-error model of the fused score (see the derivation in DESIGN.md):
+    //   |s + |q|^2 - T| <= G (|r| + |q|)^2 <= 2 G (|r|^2 + |q|^2),  G = gamma_{d + 2*D2 + 1}
+    //   D >= T (1 - gamma_{d+2})
+    // both taken with a factor-two margin.
+    const double u = 5.9604644775390625e-08;  // 2^-24
+    double G = 2.0 * (double)(d + 2 * g.D2 + 4) * u;
+    double err_abs_coef = 2.0 * G;
+    double rel_keep = 1.0 - 2.0 * (double)(d + 4) * u;
+    dim3 block(256), grid((unsigned)((n + 3) / 4));
+    hipLaunchKernelGGL(refine_kernel, grid, block, 0, stream, Q, R, d, n, g.n_pad, lists, g.S, k,
+                       col_offset, merge, err_abs_coef, rel_keep, maxnorm_bits, idx, d2, dist, lb,
+                       fail_rows, n_fail);
+    return hipGetLastError();
+}
+
+hipError_t launch_exact_rows(const float* Q, const float* R, int d, long long n, long long m, int k,
+                             long long col_offset, const int* rows, const int* n_rows, int* idx,
+                             float* d2, float* dist, hipStream_t stream) {
+    long long gmax = n < 2048 ? n : 2048;
+    if (gmax < 1) gmax = 1;
+    dim3 block(EX_NT), grid((unsigned)gmax);
+    hipLaunchKernelGGL(exact_rows_kernel, grid, block, 0, stream, Q, R, d, m, k, col_offset, rows, n_rows,
+                       idx, d2, dist);
+    return hipGetLastError();
+}
+
+}  // namespace scmiac

@@ -1,0 +1,288 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the
+golden vectors produced by the reference's own code.  Needs an MI355X.
+
+Bar: neighbour indices, anchor pairs and integer scores bit-exact; float64
+``score`` bit-exact; distances identical to the oracle's float32 value (and
+within 1e-5 relative of a float64 evaluation)."""
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle
+from scmiac_amd import _hip, anchor_search
+from scmiac_amd.preprocessing import anchors as A
+from scmiac_amd.modeling import scmiac as M
+
+
+def _dev(x, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(x)).to("cuda", dtype)
+
+
+def _mixture(seed, n, d, C=8, unit=False, offset=False):
+    rng = np.random.default_rng(seed)
+    centres = np.random.default_rng(1000 + d).normal(scale=3.0, size=(C, d))
+    X = centres[rng.integers(0, C, n)] + rng.normal(size=(n, d))
+    if offset:
+        X = X + np.random.default_rng(2000 + d).normal(scale=0.25, size=d)
+    if unit:
+        X = X / np.linalg.norm(X, axis=1, keepdims=True)
+    return X.astype(np.float32)
+
+
+def _check_knn(Q, R, k, **kw):
+    st = _hip.knn_search(_dev(Q), _dev(R), k, **kw)
+    torch.cuda.synchronize()
+    idx_o, d2_o = oracle.knn_dist2(Q, R, k)
+    np.testing.assert_array_equal(st.idx.cpu().numpy(), idx_o)
+    np.testing.assert_array_equal(st.dist2.cpu().numpy(), d2_o)  # same float32 arithmetic
+    np.testing.assert_array_equal(st.dist.cpu().numpy(), np.sqrt(d2_o, dtype=np.float32))
+    return st
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c", "dup", "tiny"])
+def test_find_neighbor_golden(golden, case):
+    f = golden["f3_find_neighbor"]
+    k = int(f[f"{case}_k"])
+    G = A.find_neighbor(f[f"{case}_U"], f[f"{case}_V"], k)
+    for name, g in zip(("G11", "G12", "G21", "G22"), G):
+        assert g.dtype == np.int32 and g.shape == f[f"{case}_{name}"].shape
+        np.testing.assert_array_equal(g, f[f"{case}_{name}"])
+
+
+@pytest.mark.parametrize("n,m,d,k", [
+    (1, 1, 1, 1), (5, 3, 2, 3), (300, 70, 16, 31), (257, 513, 30, 30), (1000, 2049, 49, 31),
+    (1500, 1500, 50, 30), (700, 900, 64, 64), (513, 777, 100, 20), (260, 300, 128, 10),
+    (100, 40, 7, 50),  # k > m: padded with -1 / inf
+])
+def test_knn_matches_oracle_shapes(n, m, d, k):
+    Q = _mixture(n + d, n, d)
+    R = _mixture(m + 7 * d, m, d, offset=True)
+    _check_knn(Q, R, k)
+
+
+def test_knn_unit_norm_and_self():
+    X = _mixture(5, 3000, 30, unit=True)
+    st = _check_knn(X, X, 31)
+    # the self table's first column is the row itself (no duplicates in this set)
+    np.testing.assert_array_equal(st.idx[:, 0].cpu().numpy(), np.arange(3000))
+
+
+def test_knn_duplicates_use_direct_evaluation():
+    """Exact duplicates tie at the shortlist edge: the certificate must fail for
+    those rows and the direct-evaluation pass must restore (D, index) order."""
+    R = _mixture(9, 2000, 30)
+    R[100:400] = R[7]          # 300 copies: more than the 64-entry shortlist holds
+    Q = np.concatenate([R[:50], _mixture(10, 200, 30)])
+    st = _check_knn(Q, R, 31)
+    assert int(st.n_uncertified.item()) > 0
+
+
+def test_knn_many_splits_and_single_split_agree():
+    Q = _mixture(21, 600, 50)
+    R = _mixture(22, 5000, 50, offset=True)
+    a = _check_knn(Q, R, 30, splits=1)
+    b = _check_knn(Q, R, 30, splits=7)
+    assert torch.equal(a.idx, b.idx)
+
+
+def test_knn_merge_over_reference_blocks():
+    """Searching reference blocks one after the other (ring / tiled mode) gives
+    the top-k of the union."""
+    Q = _mixture(31, 500, 50)
+    R = _mixture(32, 3000, 50, offset=True)
+    idx_o, d2_o = oracle.knn_dist2(Q, R, 30)
+    q = _dev(Q)
+    st = None
+    for lo, hi in ((0, 1100), (1100, 1900), (1900, 3000)):
+        st = _hip.knn_search(q, _dev(R[lo:hi]), 30, col_offset=lo, state=st, exact_fallback=False)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(st.idx.cpu().numpy(), idx_o)
+    np.testing.assert_array_equal(st.dist2.cpu().numpy(), d2_o)
+    kth = st.dist2[:, -1].double()
+    assert bool((kth < st.lower_bound).all())  # every row certified without the fallback
+
+
+def test_knn_exact_rows_alone():
+    Q = _mixture(41, 64, 30)
+    R = _mixture(42, 1500, 30)
+    st = _hip.knn_search(_dev(Q), _dev(R[:200]), 31, exact_fallback=False)
+    rows = torch.arange(64, dtype=torch.int32, device="cuda")
+    n_rows = torch.tensor([64], dtype=torch.int32, device="cuda")
+    _hip.knn_exact_rows(_dev(Q), _dev(R[200:]), 31, rows, n_rows, st, col_offset=200)
+    torch.cuda.synchronize()
+    idx_o, d2_o = oracle.knn_dist2(Q, R, 31)
+    np.testing.assert_array_equal(st.idx.cpu().numpy(), idx_o)
+    np.testing.assert_array_equal(st.dist2.cpu().numpy(), d2_o)
+
+
+def test_knn_distances_within_tolerance_of_float64():
+    Q = _mixture(51, 800, 50)
+    R = _mixture(52, 4000, 50, offset=True)
+    st = _hip.knn_search(_dev(Q), _dev(R), 30)
+    idx = st.idx.cpu().numpy()
+    ref = np.sqrt(((Q[:, None, :].astype(np.float64) - R[idx].astype(np.float64)) ** 2).sum(-1))
+    np.testing.assert_allclose(st.dist.cpu().numpy(), ref, rtol=1e-5)  # north-star tolerance
+
+
+def test_knn_rejects_bad_arguments():
+    q = torch.zeros((4, 8), device="cuda")
+    with pytest.raises(ValueError):
+        _hip.knn_search(q, q, 65)
+    with pytest.raises(ValueError):
+        _hip.knn_search(torch.zeros((4, 200), device="cuda"), torch.zeros((4, 200), device="cuda"), 3)
+    with pytest.raises(ValueError):
+        _hip.knn_search(q, torch.zeros((4, 9), device="cuda"), 3)
+
+
+def test_find_mnn_golden(golden):
+    f = golden["f1_find_mnn"]
+    for ka in (1, 5, 30):
+        got = A.find_mnn(f["G12"], f["G21"], ka)
+        assert got.dtype == np.int64
+        np.testing.assert_array_equal(got, f[f"pairs_ka{ka}"])
+    empty = A.find_mnn(f["G12_empty"], f["G21_empty"], 3)
+    assert empty.shape == (0,)
+    with pytest.raises(IndexError):
+        A.find_mnn(f["G12"], f["G21"], 31)
+    bad = f["G12"].copy()
+    bad[3, 0] = 10_000
+    with pytest.raises(IndexError):
+        A.find_mnn(bad, f["G21"], 5)
+
+
+def test_find_mnn_large_random_matches_oracle():
+    rng = np.random.default_rng(3)
+    n1, n2, k = 40_000, 35_000, 30
+    G12 = rng.integers(0, n2, size=(n1, k), dtype=np.int32)
+    G21 = rng.integers(0, n1, size=(n2, k), dtype=np.int32)
+    # plant mutual pairs so the result is not tiny
+    rows = rng.integers(0, n1, 20_000)
+    G21[G12[rows, 2], 1] = rows
+    np.testing.assert_array_equal(A.find_mnn(G12, G21, 5), oracle.find_mnn(G12, G21, 5))
+
+
+def test_score_anchor_golden(golden):
+    f = golden["f2_score_anchor"]
+    for ks in (30, 10):
+        df = A.score_anchor(f["pairs"], f["G11"], f["G12"], f["G21"], f["G22"], k_score=ks, k_local=None)
+        assert list(df.columns) == ["x1", "x2", "score"] and df["score"].dtype == np.float64
+        np.testing.assert_array_equal(df["score"].values, f[f"score_ks{ks}"])
+        raw = A._snn_raw(f["pairs"], f["G11"], f["G12"], f["G21"], f["G22"], ks)
+        np.testing.assert_array_equal(np.asarray(raw, dtype=np.int32), f[f"raw_ks{ks}"])
+    with pytest.raises(ValueError):
+        A.score_anchor(np.array([]), f["G11"], f["G12"], f["G21"], f["G22"], k_local=None)
+
+
+class _FakeAnnData:
+    def __init__(self, X, obsm=None, obs=None):
+        self.X = np.asarray(X)
+        self.shape = self.X.shape
+        self.obsm = dict(obsm or {})
+        self.obs = obs
+        self.var = type("V", (), {"index": pd.Index([f"g{i}" for i in range(self.X.shape[1])])})()
+
+
+def _run_precomputed(f):
+    a1 = _FakeAnnData(np.zeros((f["pre_U"].shape[0], 3)), obsm={"lat": f["pre_U"]})
+    a2 = _FakeAnnData(np.zeros((f["pre_V"].shape[0], 3)), obsm={"lat": f["pre_V"]})
+    integ = A.SeuratIntegration()
+    integ.find_anchor([a1, a2], k_local=None, key_anchor="lat", dim_red="precomputed", k_anchor=5,
+                      k_score=30, k_filter=None, alignments=[[[0], [1]]])
+    return integ
+
+
+def test_find_anchor_precomputed_golden(golden, capsys):
+    f = golden["f4_find_anchor"]
+    integ = _run_precomputed(f)
+    adf = integ.anchor[(0, 1)]
+    np.testing.assert_array_equal(adf["x1"].values, f["pre_x1"])
+    np.testing.assert_array_equal(adf["x2"].values, f["pre_x2"])
+    np.testing.assert_array_equal(adf["score"].values, f["pre_score"])
+    assert adf["x1"].dtype == np.int64 and adf["score"].dtype == np.float64
+    np.testing.assert_array_equal(integ.raw_anchor[(0, 1)], f["pre_raw"])
+    for name, g in zip(("G11", "G12", "G21", "G22"), integ.mutual_knn[(0, 1)]):
+        np.testing.assert_array_equal(g, f[f"pre_{name}"])
+    assert "Find Anchors using k=30" in capsys.readouterr().out
+
+
+@pytest.mark.parametrize("ct_filter,tag", [(True, "filt"), (False, "nofilt")])
+def test_label_filter_and_csv_golden(golden, ct_filter, tag):
+    f = golden["f4_find_anchor"]
+    integ = _run_precomputed(f)
+    df, n_pass = M.label_filter(integ, f["pre_lab1"], f["pre_lab2"], ct_filter=ct_filter)
+    assert list(df.columns) == ["x1", "x2", "score", "x1_ct", "x2_ct", "is_same"]
+    np.testing.assert_array_equal(df["x1"].values, f[f"{tag}_x1"])
+    np.testing.assert_array_equal(df["x2"].values, f[f"{tag}_x2"])
+    np.testing.assert_array_equal(df["score"].values, f[f"{tag}_score"])
+    np.testing.assert_array_equal(df["is_same"].values, f[f"{tag}_is_same"])
+    np.testing.assert_array_equal(df.index.values, f[f"{tag}_index"])
+    assert n_pass == len(f["nofilt_x1"])
+    assert df.to_csv(index=False) == str(f[f"{tag}_csv"])  # anchors.csv text, byte for byte
+
+
+def test_find_anchor_cca_branch_golden(golden):
+    """Whole "cca" branch: host CCA (same scikit-learn calls as the reference) feeding
+    the GPU search; anchors and scores must equal the reference's."""
+    f = golden["f4_find_anchor"]
+    integ = A.SeuratIntegration()
+    integ.find_anchor([_FakeAnnData(f["cca_X1"]), _FakeAnnData(f["cca_X2"])], k_local=None, key_anchor="X",
+                      dim_red="cca", max_cc_cells=50000, k_anchor=5, k_score=30, scale1=True, scale2=True,
+                      n_components=20, k_filter=None, alignments=[[[0], [1]]])
+    np.testing.assert_allclose(integ.U, f["cca_U"], rtol=0, atol=1e-12)
+    adf = integ.anchor[(0, 1)]
+    np.testing.assert_array_equal(adf["x1"].values, f["cca_x1"])
+    np.testing.assert_array_equal(adf["x2"].values, f["cca_x2"])
+    np.testing.assert_array_equal(adf["score"].values, f["cca_score"])
+
+
+def test_rare_label_atlas_against_oracle():
+    """200 labels, 50 of them rare (0.1 % each), 10 % label noise on the ATAC side:
+    the filtered anchor table must equal the oracle's, rare labels included."""
+    rng = np.random.default_rng(3003)
+    C, d, n1, n2 = 200, 50, 12_000, 11_000
+    prior = np.r_[np.full(50, 0.001), (1.0 / np.arange(1, 151)) / (1.0 / np.arange(1, 151)).sum() * 0.95]
+    centres = rng.normal(scale=3.0, size=(C, d))
+    l1, l2 = rng.choice(C, n1, p=prior), rng.choice(C, n2, p=prior)
+    U = (centres[l1] + rng.normal(size=(n1, d))).astype(np.float32)
+    V = (centres[l2] + rng.normal(scale=0.25, size=d) + rng.normal(size=(n2, d))).astype(np.float32)
+    noisy = l2.copy()
+    flip = rng.random(n2) < 0.10
+    noisy[flip] = (noisy[flip] + rng.integers(1, C, flip.sum())) % C
+
+    odf, _, _ = oracle.pairwise_anchors(U, V, k_anchor=5, k_score=30)
+    want = oracle.label_filter(odf, l1, noisy, ct_filter=True)
+
+    tables = anchor_search.find_neighbor_device(_dev(U), _dev(V), 30)
+    scores, n_pairs = anchor_search.mnn_and_score(tables, 5, 30)
+    c1, c2 = anchor_search.label_codes(l1, noisy)
+    got = anchor_search.filter_anchors(scores, n_pairs, c1, c2, ct_filter=True)
+    np.testing.assert_array_equal(got.x1, want["x1"].values)
+    np.testing.assert_array_equal(got.x2, want["x2"].values)
+    np.testing.assert_array_equal(got.score, want["score"].values)
+    np.testing.assert_array_equal(got.index, want.index.values)
+    rare_kept = np.isin(l1[got.x1], np.arange(50)).sum()
+    assert rare_kept == np.isin(l1[want["x1"].values], np.arange(50)).sum()
+
+
+def test_large_search_sampled_against_oracle():
+    """100k x 100k, d = 50 (the single-GPU benchmark shape): 2 000 sampled rows
+    checked bit-exactly, plus size-independent properties on all rows."""
+    n = m = 100_000
+    g = torch.Generator(device="cuda").manual_seed(1001)
+    centres = torch.randn((50, 50), device="cuda", generator=g) * 3
+    Q = centres[torch.randint(0, 50, (n,), device="cuda", generator=g)] + torch.randn((n, 50), device="cuda", generator=g)
+    R = centres[torch.randint(0, 50, (m,), device="cuda", generator=g)] + torch.randn((m, 50), device="cuda", generator=g) + 0.1
+    st = _hip.knn_search(Q, R, 30)
+    torch.cuda.synchronize()
+    d2 = st.dist2
+    assert bool((d2[:, 1:] >= d2[:, :-1]).all())                      # rows sorted
+    assert bool((st.idx >= 0).all()) and bool((st.idx < m).all())
+    srt = torch.sort(st.idx, dim=1).values
+    assert bool((srt[:, 1:] != srt[:, :-1]).all())                    # no reference twice in a row
+    rows = np.random.default_rng(5).choice(n, 2000, replace=False)
+    idx_o, d2_o = oracle.knn_dist2(Q[rows].cpu().numpy(), R.cpu().numpy(), 30)
+    np.testing.assert_array_equal(st.idx[rows].cpu().numpy(), idx_o)
+    np.testing.assert_array_equal(st.dist2[rows].cpu().numpy(), d2_o)

@@ -1,0 +1,91 @@
+"""Host-side checks that need no GPU: the C-ABI library loads and exports every
+symbol the header declares, and the drop-in API validates arguments like the
+reference does."""
+import ctypes
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _declared_symbols():
+    text = (ROOT / "include" / "scmiac_hip.h").read_text()
+    return sorted(set(re.findall(r"SCMIAC_API\s+[\w\s\*]+?\b(scmiac_\w+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from scmiac_amd import _hip
+
+    declared = _declared_symbols()
+    assert len(declared) >= 10
+    lib = ctypes.CDLL(str(_hip.LIB_PATH))
+    for name in declared:
+        assert hasattr(lib, name), f"{name} is declared in include/scmiac_hip.h but not exported"
+    assert sorted(_hip.EXPORTED_SYMBOLS) == declared
+    assert _hip.load_library().scmiac_version() >= 1000
+
+
+def test_size_queries_and_argument_checks_without_gpu():
+    from scmiac_amd import _hip
+
+    lib = _hip.load_library()
+    n = ctypes.c_size_t(0)
+    assert lib.scmiac_knn_workspace_size(1000, 2000, 50, 30, 0, ctypes.byref(n)) == 0
+    assert n.value > 1000 * 64 * 8
+    assert lib.scmiac_knn_workspace_size(10, 10, 500, 30, 0, ctypes.byref(n)) == 1
+    assert b"dimension" in lib.scmiac_last_error()
+    assert lib.scmiac_knn_workspace_size(10, 10, 50, 65, 0, ctypes.byref(n)) == 1
+    assert lib.scmiac_compact_workspace_size(12345, ctypes.byref(n)) == 0 and n.value >= 2 * 12345
+
+
+def test_no_cpu_fallback_without_device():
+    import torch
+    from scmiac_amd import _hip
+    from scmiac_amd.preprocessing import anchors as A
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    with pytest.raises(_hip.ScmiacHipError):
+        A.find_neighbor(np.zeros((10, 4), np.float32), np.zeros((10, 4), np.float32), 3)
+
+
+def test_find_anchor_rejects_unknown_dim_red():
+    from scmiac_amd.preprocessing.anchors import SeuratIntegration
+
+    with pytest.raises(ValueError, match="is not supported"):
+        SeuratIntegration().find_anchor([], dim_red="umap")
+
+
+def test_find_anchors_mode_v():
+    import pandas as pd
+    from scmiac_amd import find_anchors
+
+    class AD:
+        def __init__(self, n):
+            self.shape = (n, 5)
+            self.obs = pd.DataFrame({"cell_type": [f"t{i % 3}" for i in range(n)]})
+
+    df = find_anchors(AD(7), AD(7), mode="v")
+    assert list(df.columns) == ["x1", "x2", "x1_ct"] and len(df) == 7
+    with pytest.raises(ValueError, match="must be equal when mode='v'"):
+        find_anchors(AD(7), AD(8), mode="v")
+
+
+def test_min_max_is_the_reference_formula(golden):
+    from scmiac_amd.preprocessing.anchors import min_max
+
+    f = golden["f2_score_anchor"]
+    np.testing.assert_array_equal(min_max([int(v) for v in f["minmax_in"]]), f["minmax_out"])
+
+
+def test_label_codes_follow_string_equality():
+    from scmiac_amd.anchor_search import label_codes
+
+    a = np.array(["B", "T", 1, None], dtype=object)
+    b = np.array(["T", "1", "None", "x"], dtype=object)
+    c1, c2 = label_codes(a, b)
+    eq = a.astype(str)[:, None] == b.astype(str)[None, :]
+    np.testing.assert_array_equal(c1[:, None] == c2[None, :], eq)
