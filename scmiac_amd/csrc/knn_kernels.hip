@@ -34,6 +34,9 @@ __device__ __forceinline__ float ord2f(unsigned o) {
     unsigned u = (o & 0x80000000u) ? (o ^ 0x80000000u) : ~o;
     return __uint_as_float(u);
 }
+// correctly rounded float32 square root: the double result rounded once more is exact
+// for sqrt because 53 >= 2*24 + 2
+__device__ __forceinline__ float sqrt_rn_f32(float x) { return (float)sqrt((double)x); }
 __device__ __forceinline__ u64 umin64(u64 a, u64 b) { return a < b ? a : b; }
 __device__ __forceinline__ u64 umax64(u64 a, u64 b) { return a < b ? b : a; }
 
@@ -382,7 +385,7 @@ __global__ __launch_bounds__(256) void refine_kernel(
         float D = __uint_as_float((unsigned)(best >> 32));
         out_idx[q * k + lane] = valid ? (int)(unsigned)best : -1;
         out_d2[q * k + lane] = valid ? D : __builtin_inff();
-        if (out_dist) out_dist[q * k + lane] = valid ? __fsqrt_rn(D) : __builtin_inff();
+        if (out_dist) out_dist[q * k + lane] = valid ? sqrt_rn_f32(D) : __builtin_inff();
     }
     if (lane == 0) {
         lower_bound[q] = lb;
@@ -491,7 +494,7 @@ __global__ __launch_bounds__(EX_NT) void exact_rows_kernel(
                 float D = __uint_as_float((unsigned)(key >> 32));
                 idx_io[q * k + tid] = valid ? (int)(unsigned)key : -1;
                 d2_io[q * k + tid] = valid ? D : __builtin_inff();
-                if (dist_out) dist_out[q * k + tid] = valid ? __fsqrt_rn(D) : __builtin_inff();
+                if (dist_out) dist_out[q * k + tid] = valid ? sqrt_rn_f32(D) : __builtin_inff();
             }
         }
     }
