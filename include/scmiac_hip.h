@@ -148,12 +148,14 @@ SCMIAC_API int scmiac_anchor_filter(const int64_t *pairs, const int64_t *n_pairs
                          void *stream);
 
 /*
- * Optional in-library timing of the fused distance + top-k kernel: when enabled,
- * scmiac_knn_search brackets that kernel's launch with HIP events on `stream`;
- * scmiac_knn_last_fused_ms waits for them and returns the elapsed milliseconds.
+ * Optional in-library timing of the fused distance + top-k kernel (no counterpart
+ * in the reference).  While enabled, every scmiac_knn_search brackets that kernel's
+ * launch with a pair of HIP events on `stream` (up to 256 searches; enabling again
+ * restarts the count).  scmiac_knn_fused_ms waits for the recorded events and
+ * returns the summed kernel time and the number of launches it covers.
  */
 SCMIAC_API int scmiac_knn_set_timing(int enabled);
-SCMIAC_API int scmiac_knn_last_fused_ms(float *ms);
+SCMIAC_API int scmiac_knn_fused_ms(float *total_ms, int *launches);
 
 #ifdef __cplusplus
 }

@@ -42,6 +42,15 @@ static inline float dist2_f32(const float *a, const float *b, int d) {
     return acc;
 }
 
+/* threads an oracle_knn call with nthreads <= 0 will use */
+ORACLE_API int oracle_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
 /* (D, idx) lexicographic "less than" */
 static inline int key_less(float da, int64_t ia, float db, int64_t ib) {
     return (da < db) || (da == db && ia < ib);

@@ -67,10 +67,10 @@ def _p(a, ct):
 
 
 def host_threads() -> int:
-    try:
-        return len(os.sched_getaffinity(0))
-    except AttributeError:  # pragma: no cover
-        return os.cpu_count() or 1
+    """Threads the C search uses by default (OpenMP's choice, e.g. OMP_NUM_THREADS)."""
+    lib = _lib()
+    lib.oracle_max_threads.restype = ctypes.c_int
+    return int(lib.oracle_max_threads())
 
 
 # --------------------------------------------------------------------------- k-NN

@@ -37,7 +37,7 @@ _SIGNATURES = {
     "scmiac_anchor_filter": ([_vp, _vp, _i64, _vp, _dbl, _dbl, _dbl, _vp, _i64, _vp, _i64, _i32, _vp, _vp,
                               _vp, _vp, _vp, _vp, _vp, _sz, _vp], _c.c_int),
     "scmiac_knn_set_timing": ([_i32], _c.c_int),
-    "scmiac_knn_last_fused_ms": ([_c.POINTER(_c.c_float)], _c.c_int),
+    "scmiac_knn_fused_ms": ([_c.POINTER(_c.c_float), _c.POINTER(_c.c_int)], _c.c_int),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -240,7 +240,9 @@ def set_timing(enabled: bool):
     _check(load_library().scmiac_knn_set_timing(1 if enabled else 0))
 
 
-def last_fused_ms() -> float:
+def fused_ms():
+    """(summed fused-kernel milliseconds, launches) since timing was enabled."""
     ms = ctypes.c_float(0.0)
-    _check(load_library().scmiac_knn_last_fused_ms(ctypes.byref(ms)))
-    return float(ms.value)
+    cnt = ctypes.c_int(0)
+    _check(load_library().scmiac_knn_fused_ms(ctypes.byref(ms), ctypes.byref(cnt)))
+    return float(ms.value), int(cnt.value)

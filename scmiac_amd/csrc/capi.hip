@@ -64,9 +64,12 @@ static int check_knn_args(int64_t n, int64_t m, int d, int k) {
     return SCMIAC_OK;
 }
 
+// optional timing of the fused kernel: one event pair per search since timing was enabled
+static constexpr int kMaxTimed = 256;
 static bool g_timing = false;
-static hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
-static bool g_ev_valid = false;
+static hipEvent_t g_ev0[kMaxTimed], g_ev1[kMaxTimed];
+static int g_ev_created = 0;
+static int g_ev_used = 0;
 
 extern "C" {
 
@@ -106,17 +109,19 @@ int scmiac_knn_search(const float* q, int64_t n, const float* r, int64_t m, int 
     HIP_TRY(hipMemsetAsync(n_uncertified, 0, sizeof(int32_t), stream), "memset n_uncertified");
     HIP_TRY(launch_pack(q, n, d, g, -2.0f, w.qp, nullptr, g.n_pad, w.maxnorm, stream), "pack queries");
     HIP_TRY(launch_pack(r, m, d, g, 1.0f, w.rp, w.rnorm, g.m_pad, w.maxnorm, stream), "pack references");
-    if (g_timing) {
-        if (!g_ev0) {
-            HIP_TRY(hipEventCreate(&g_ev0), "event create");
-            HIP_TRY(hipEventCreate(&g_ev1), "event create");
+    const bool timed = g_timing && g_ev_used < kMaxTimed;
+    if (timed) {
+        if (g_ev_used >= g_ev_created) {
+            HIP_TRY(hipEventCreate(&g_ev0[g_ev_created]), "event create");
+            HIP_TRY(hipEventCreate(&g_ev1[g_ev_created]), "event create");
+            ++g_ev_created;
         }
-        HIP_TRY(hipEventRecord(g_ev0, stream), "event record");
+        HIP_TRY(hipEventRecord(g_ev0[g_ev_used], stream), "event record");
     }
     HIP_TRY(launch_fused(g, w.qp, w.rp, w.rnorm, w.lists, n, stream), "fused distance + top-k");
-    if (g_timing) {
-        HIP_TRY(hipEventRecord(g_ev1, stream), "event record");
-        g_ev_valid = true;
+    if (timed) {
+        HIP_TRY(hipEventRecord(g_ev1[g_ev_used], stream), "event record");
+        ++g_ev_used;
     }
     HIP_TRY(launch_refine(q, r, d, n, g, w.lists, k, col_offset, merge, w.maxnorm, idx, dist2, dist,
                           lower_bound, uncertified_rows, n_uncertified, stream),
@@ -211,15 +216,21 @@ int scmiac_anchor_filter(const int64_t* pairs, const int64_t* n_pairs, int64_t n
 
 int scmiac_knn_set_timing(int enabled) {
     g_timing = enabled != 0;
-    g_ev_valid = false;
+    g_ev_used = 0;
     return SCMIAC_OK;
 }
 
-int scmiac_knn_last_fused_ms(float* ms) {
-    if (!ms) return fail(SCMIAC_ERR_ARG, "ms is NULL");
-    if (!g_ev_valid) return fail(SCMIAC_ERR_ARG, "no timed search has run");
-    HIP_TRY(hipEventSynchronize(g_ev1), "event synchronize");
-    HIP_TRY(hipEventElapsedTime(ms, g_ev0, g_ev1), "event elapsed");
+int scmiac_knn_fused_ms(float* total_ms, int* launches) {
+    if (!total_ms || !launches) return fail(SCMIAC_ERR_ARG, "NULL output pointer");
+    float sum = 0.f;
+    for (int i = 0; i < g_ev_used; ++i) {
+        float ms = 0.f;
+        HIP_TRY(hipEventSynchronize(g_ev1[i]), "event synchronize");
+        HIP_TRY(hipEventElapsedTime(&ms, g_ev0[i], g_ev1[i]), "event elapsed");
+        sum += ms;
+    }
+    *total_ms = sum;
+    *launches = g_ev_used;
     return SCMIAC_OK;
 }
 
