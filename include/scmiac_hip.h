@@ -148,6 +148,16 @@ SCMIAC_API int scmiac_anchor_filter(const int64_t *pairs, const int64_t *n_pairs
                          void *stream);
 
 /*
+ * Diagnostic aid (no counterpart in the reference).  When the environment variable
+ * SCMIAC_FUSED_DIAG=1 is set, the fused kernel of scmiac_knn_search writes eight
+ * uint64 counters per wave into the workspace at `offset`:
+ *   {wave cycles, cycles in the candidate path, cycles merging shortlists,
+ *    candidate-path entries, shortlist merges, candidates taken, 0, 0}.
+ */
+SCMIAC_API int scmiac_knn_diag_region(int64_t n, int64_t m, int d, int k, int splits, size_t *offset,
+                                      size_t *bytes, int *waves);
+
+/*
  * Optional in-library timing of the fused distance + top-k kernel (no counterpart
  * in the reference).  While enabled, every scmiac_knn_search brackets that kernel's
  * launch with a pair of HIP events on `stream` (up to 256 searches; enabling again

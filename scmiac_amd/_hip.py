@@ -36,6 +36,8 @@ _SIGNATURES = {
                          _c.c_int),
     "scmiac_anchor_filter": ([_vp, _vp, _i64, _vp, _dbl, _dbl, _dbl, _vp, _i64, _vp, _i64, _i32, _vp, _vp,
                               _vp, _vp, _vp, _vp, _vp, _sz, _vp], _c.c_int),
+    "scmiac_knn_diag_region": ([_i64, _i64, _i32, _i32, _i32, _c.POINTER(_sz), _c.POINTER(_sz),
+                                _c.POINTER(_c.c_int)], _c.c_int),
     "scmiac_knn_set_timing": ([_i32], _c.c_int),
     "scmiac_knn_fused_ms": ([_c.POINTER(_c.c_float), _c.POINTER(_c.c_int)], _c.c_int),
 }
@@ -234,6 +236,17 @@ def anchor_filter(pairs, n_pairs, raw_score, p_lo, p_hi, codes1, codes2, *, thre
                                         _ptr(out_score), _ptr(out_same), _ptr(out_index), _ptr(counts),
                                         _ptr(all_score), _ptr(ws), ws.numel(), _stream()))
     return out_pairs, out_score, out_same, out_index, counts, all_score
+
+
+def knn_diag(n, m, d, k, splits=0, device=None):
+    """Per-wave counters of the last fused kernel (needs SCMIAC_FUSED_DIAG=1 at search time):
+    int64 array [waves, 8]."""
+    off, nbytes, waves = ctypes.c_size_t(0), ctypes.c_size_t(0), ctypes.c_int(0)
+    _check(load_library().scmiac_knn_diag_region(n, m, d, k, splits, ctypes.byref(off), ctypes.byref(nbytes),
+                                                 ctypes.byref(waves)))
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    ws = _ws_cache[device]
+    return ws[off.value:off.value + nbytes.value].view(torch.int64).view(waves.value, 8).cpu().numpy()
 
 
 def set_timing(enabled: bool):

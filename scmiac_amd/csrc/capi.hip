@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/scmiac_hip.h"
@@ -35,6 +36,8 @@ struct KnnWs {
     float* rnorm;
     unsigned long long* lists;
     unsigned* maxnorm;
+    unsigned long long* diag;  // per-wave counters of the fused kernel (diagnostic runs)
+    size_t diag_offset, diag_bytes;
     size_t total;
 };
 static KnnWs knn_carve(void* ws, long long n, const KnnGeometry& g) {
@@ -45,13 +48,17 @@ static KnnWs knn_carve(void* ws, long long n, const KnnGeometry& g) {
     w.qp = reinterpret_cast<float*>(p + off);
     off += up256(sizeof(float) * (size_t)g.n_pad * g.rowf);
     w.rp = reinterpret_cast<float*>(p + off);
-    off += up256(sizeof(float) * (size_t)g.m_pad * g.rowf);
+    off += up256(sizeof(float) * (size_t)g.m_pad * g.ls);
     w.rnorm = reinterpret_cast<float*>(p + off);
     off += up256(sizeof(float) * (size_t)g.m_pad);
     w.lists = reinterpret_cast<unsigned long long*>(p + off);
     off += up256(sizeof(unsigned long long) * (size_t)g.S * g.n_pad * 64);
     w.maxnorm = reinterpret_cast<unsigned*>(p + off);
     off += 256;
+    w.diag = reinterpret_cast<unsigned long long*>(p + off);
+    w.diag_offset = off;
+    w.diag_bytes = sizeof(unsigned long long) * 8 * (size_t)g.nqb * g.S * g.nw;
+    off += up256(w.diag_bytes);
     w.total = off;
     return w;
 }
@@ -87,6 +94,20 @@ int scmiac_knn_workspace_size(int64_t n, int64_t m, int d, int k, int splits, si
     return SCMIAC_OK;
 }
 
+int scmiac_knn_diag_region(int64_t n, int64_t m, int d, int k, int splits, size_t* offset, size_t* bytes,
+                           int* waves) {
+    if (!offset || !bytes || !waves) return fail(SCMIAC_ERR_ARG, "NULL output pointer");
+    int rc = check_knn_args(n, m, d, k);
+    if (rc) return rc;
+    KnnGeometry g = knn_geometry(n, m, d, splits);
+    if (g.D2 < 0) return fail(SCMIAC_ERR_ARG, "unsupported feature dimension %d", d);
+    KnnWs w = knn_carve(nullptr, n, g);
+    *offset = w.diag_offset;
+    *bytes = w.diag_bytes;
+    *waves = g.nqb * g.S * g.nw;
+    return SCMIAC_OK;
+}
+
 int scmiac_knn_search(const float* q, int64_t n, const float* r, int64_t m, int d, int k,
                       int64_t col_offset, int merge, int splits, int32_t* idx, float* dist2, float* dist,
                       double* lower_bound, int32_t* uncertified_rows, int32_t* n_uncertified,
@@ -107,8 +128,8 @@ int scmiac_knn_search(const float* q, int64_t n, const float* r, int64_t m, int 
 
     HIP_TRY(hipMemsetAsync(w.maxnorm, 0, 256, stream), "memset maxnorm");
     HIP_TRY(hipMemsetAsync(n_uncertified, 0, sizeof(int32_t), stream), "memset n_uncertified");
-    HIP_TRY(launch_pack(q, n, d, g, -2.0f, w.qp, nullptr, g.n_pad, w.maxnorm, stream), "pack queries");
-    HIP_TRY(launch_pack(r, m, d, g, 1.0f, w.rp, w.rnorm, g.m_pad, w.maxnorm, stream), "pack references");
+    HIP_TRY(launch_pack(q, n, d, g, -2.0f, w.qp, g.rowf, nullptr, g.n_pad, w.maxnorm, stream), "pack queries");
+    HIP_TRY(launch_pack(r, m, d, g, 1.0f, w.rp, g.ls, w.rnorm, g.m_pad, w.maxnorm, stream), "pack references");
     const bool timed = g_timing && g_ev_used < kMaxTimed;
     if (timed) {
         if (g_ev_used >= g_ev_created) {
@@ -118,7 +139,9 @@ int scmiac_knn_search(const float* q, int64_t n, const float* r, int64_t m, int 
         }
         HIP_TRY(hipEventRecord(g_ev0[g_ev_used], stream), "event record");
     }
-    HIP_TRY(launch_fused(g, w.qp, w.rp, w.rnorm, w.lists, n, stream), "fused distance + top-k");
+    const char* dg = getenv("SCMIAC_FUSED_DIAG");  // diagnostic runs: per-wave cycle counters
+    HIP_TRY(launch_fused(g, w.qp, w.rp, w.rnorm, w.lists, n, (dg && dg[0] == '1') ? w.diag : nullptr, stream),
+            "fused distance + top-k");
     if (timed) {
         HIP_TRY(hipEventRecord(g_ev1[g_ev_used], stream), "event record");
         ++g_ev_used;

@@ -14,8 +14,10 @@ namespace scmiac {
 struct KnnGeometry {
     int D2;                // MFMA K steps per tile (two features per step)
     int D2P;               // D2 rounded up to a multiple of 4
-    int rowf;              // floats per packed row (2 * D2P)
+    int rowf;              // feature floats per packed row (2 * D2P)
+    int ls;                // row stride of the packed reference image (features, zero pad)
     int RT;                // reference rows per LDS stage
+    int nw;                // waves per block of the fused kernel
     int qpb;               // queries per block
     int nqb;               // query blocks
     int S;                 // reference chunks searched independently
@@ -28,9 +30,10 @@ int knn_pick_d2(int d);
 KnnGeometry knn_geometry(long long n, long long m, int d, int splits);
 
 hipError_t launch_pack(const float* X, long long n, int d, const KnnGeometry& g, float scale, float* Xp,
-                       float* norms, long long n_pad, unsigned* maxnorm_bits, hipStream_t stream);
+                       int ld, float* norms, long long n_pad, unsigned* maxnorm_bits, hipStream_t stream);
 hipError_t launch_fused(const KnnGeometry& g, const float* Qp, const float* Rp, const float* rnorm,
-                        unsigned long long* lists, long long n, hipStream_t stream);
+                        unsigned long long* lists, long long n, unsigned long long* diag,
+                        hipStream_t stream);
 hipError_t launch_refine(const float* Q, const float* R, int d, long long n, const KnnGeometry& g,
                          const unsigned long long* lists, int k, long long col_offset, int merge,
                          const unsigned* maxnorm_bits, int* idx, float* d2, float* dist, double* lb,

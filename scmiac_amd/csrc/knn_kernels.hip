@@ -14,6 +14,10 @@
 //   exact_rows     rows whose certificate failed are searched by direct evaluation
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <type_traits>
 
 #include "kernels.h"
 
@@ -67,26 +71,27 @@ __device__ __forceinline__ u64 wave_merge(u64 key, int lane) {
 }
 
 // --------------------------------------------------------------------------------
-// pack_rows: X[n][d] -> Xp[n_pad][2*D2P] with lane-half-major features
+// pack_rows: X[n][d] -> Xp[n_pad][ld] with lane-half-major features
 //   Xp[row][h*D2P + s] = scale * X[row][h*D2 + s]   (0 where h*D2+s >= d or s >= D2)
 // so that lane half h of an MFMA 32x32x2 step s reads feature (h, s) with one aligned
-// 16-byte LDS read per four steps.  norms[row] = fmaf chain of x_i^2 (feature order),
-// +inf on the padding rows (they can then never be candidates).
+// 16-byte LDS read per four steps; columns 2*D2P..ld-1 are zero (a block of rows is then
+// one contiguous image of an LDS stage).  norms[row] = fmaf chain of x_i^2 (feature
+// order), 1.7e38 on the padding rows (they can then never be candidates).
 // --------------------------------------------------------------------------------
 __global__ void pack_rows_kernel(const float* __restrict__ X, long long n, int d, int D2, int D2P,
-                                 float scale, float* __restrict__ Xp, float* __restrict__ norms,
-                                 long long n_pad, unsigned* __restrict__ maxnorm_bits) {
+                                 float scale, float* __restrict__ Xp, int ld,
+                                 float* __restrict__ norms, long long n_pad,
+                                 unsigned* __restrict__ maxnorm_bits) {
     long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n_pad) return;
     const int rowf = 2 * D2P;
-    float* dst = Xp + row * rowf;
+    float* dst = Xp + row * ld;
     if (row >= n) {
-        for (int c = 0; c < rowf; ++c) dst[c] = 0.0f;
-        if (norms) norms[row] = __builtin_inff();
+        for (int c = 0; c < ld; ++c) dst[c] = 0.0f;
+        if (norms) norms[row] = __uint_as_float(0x7f000000u);  // finite, above every real score
         return;
     }
     const float* src = X + row * d;
-    float acc = 0.0f;
     for (int h = 0; h < 2; ++h) {
         for (int s = 0; s < D2P; ++s) {
             int f = h * D2 + s;
@@ -94,8 +99,10 @@ __global__ void pack_rows_kernel(const float* __restrict__ X, long long n, int d
             dst[h * D2P + s] = v * scale;
         }
     }
-    for (int i = 0; i < d; ++i) acc = __fmaf_rn(src[i], src[i], acc);
+    for (int c = rowf; c < ld; ++c) dst[c] = 0.0f;
     if (norms) {
+        float acc = 0.0f;
+        for (int i = 0; i < d; ++i) acc = __fmaf_rn(src[i], src[i], acc);
         norms[row] = acc;
         atomicMax(maxnorm_bits, __float_as_uint(acc));  // acc >= 0: bit order == value order
     }
@@ -103,19 +110,31 @@ __global__ void pack_rows_kernel(const float* __restrict__ X, long long n, int d
 
 // --------------------------------------------------------------------------------
 // fused_knn
-//   block = NW waves, each wave owns 32 queries (MFMA B operand, columns of the
-//   32x32 result tile) for the whole pass; all waves share the reference stage in LDS
-//   (MFMA A operand, rows).  Lane l: query j = l & 31, reference rows
-//   (r & 3) + 8 (r >> 2) + 4 (l >> 5) of the tile in accumulator register r.
+//   block = NW waves, each wave owns 32 queries for the whole pass (MFMA B operand,
+//   columns of the 32x32 result tile, kept in registers); all waves share the reference
+//   stage in LDS (MFMA A operand, rows).  Lane l: query j = l & 31; accumulator register
+//   r holds the score of reference row (r & 3) + 8 (r >> 2) + 4 (l >> 5) of the subtile,
+//   so each lane tests its 16 scores against one threshold, its query's.
+//   Selection works on KEYS: the score with its low four mantissa bits replaced by the
+//   register number r.  A key is a float within 16 ulp of the score, the 16 keys of a
+//   lane are distinct, and the smallest key names its own register -- so the candidate
+//   path needs no search for "which reference was it".  The 16-ulp perturbation is part
+//   of the error bound the refine kernel's certificate uses.
 // --------------------------------------------------------------------------------
-template <int D2>
+static constexpr unsigned KEY_MASK = 0xfffffff0u;
+static constexpr unsigned TAU_MAX_BITS = 0x7f000000u;  // 1.7e38: above every real score, below inf
+__device__ __forceinline__ float score_key(float score, int r) {
+    return __uint_as_float((__float_as_uint(score) & KEY_MASK) | (unsigned)r);
+}
+template <int D2, int NW_, int RT_>
 struct FusedCfg {
     static constexpr int D2P = (D2 + 3) & ~3;
-    static constexpr int ROWF = 2 * D2P;  // floats per packed row
-    // LDS row stride: an odd number of 16-byte slots -> conflict-free ds_read_b128
-    static constexpr int LS = ROWF + (((ROWF / 4) % 2 == 0) ? 4 : 0);
-    static constexpr int RT = (D2 <= 32) ? 128 : 64;  // reference rows per LDS stage
-    static constexpr int NW = 8;                       // waves per block
+    static constexpr int ROWF = 2 * D2P;  // feature floats per packed row
+    // row stride of the reference image (global and LDS): an odd number of 16-byte slots
+    // per row keeps the ds_read_b128 fragment reads conflict-free
+    static constexpr int LS = ROWF + (((ROWF / 4) % 2 == 0) ? 4 : 8);
+    static constexpr int RT = RT_;                     // reference rows per LDS stage
+    static constexpr int NW = NW_;                     // waves per block
     static constexpr int PCAP = 32;                    // pending candidates per query
     static constexpr int QPB = NW * 32;                // queries per block
     static constexpr size_t lds_bytes() {
@@ -123,6 +142,35 @@ struct FusedCfg {
                sizeof(unsigned) * (NW * 32);
     }
 };
+
+// One wave-wide LDS-DMA load: every lane fetches 16 (or 4) bytes from its own global
+// address and the data lands at the wave-uniform LDS byte address lds_dst + lane * size.
+// The compiler does not count these loads: the caller waits with s_waitcnt vmcnt before
+// the barrier that publishes the data.  M0 (the LDS base of the DMA) is saved and restored
+// inside the statement because the compiler reserves it.
+__device__ __forceinline__ void lds_dma_16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+__device__ __forceinline__ void lds_dma_4(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+// 16-byte LDS read through an LDS-address-space pointer (stays one ds_read_b128)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 lds_read_b128(const float* p) {
+    f32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(
+        (const __attribute__((address_space(3))) void*)p);
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
 
 // Merge query q's pending candidates into its 64-entry shortlist (global memory),
 // all 64 lanes cooperating.  Returns the new threshold (score of the 64th entry).
@@ -144,25 +192,33 @@ __device__ __forceinline__ float flush_query(unsigned c, const uint2* pend_q, u6
     return ord2f(top);
 }
 
-template <int D2>
-__global__ __launch_bounds__(FusedCfg<D2>::NW * 64, 2) void fused_knn_kernel(
+template <int D2, int NW_, int RT_>
+__global__ __launch_bounds__(NW_ * 64, 2) void fused_knn_kernel(
     const float* __restrict__ Qp,     // [n_pad][ROWF], already scaled by -2
-    const float* __restrict__ Rp,     // [m_pad][ROWF]
-    const float* __restrict__ rnorm,  // [m_pad]
+    const float* __restrict__ Rp,     // [m_pad][LS], zero pad columns
+    const float* __restrict__ rnorm,  // [m_pad], 1.7e38 on padding rows
     u64* __restrict__ lists,          // [S][n_pad][64]
-    long long n, long long n_pad, int nqb, long long chunk_rows) {
-    using C = FusedCfg<D2>;
+    long long n, long long n_pad, int nqb, long long chunk_rows, int ablate,
+    u64* __restrict__ diag /* per wave 8 counters, or NULL (diagnostic runs only) */) {
+    using C = FusedCfg<D2, NW_, RT_>;
     constexpr int D2P = C::D2P, ROWF = C::ROWF, LS = C::LS, RT = C::RT, NW = C::NW;
-    constexpr int PCAP = C::PCAP, NT = NW * 64, NSUB = RT / 32;
-    constexpr int F4_ROW = ROWF / 4;
-    constexpr int F4_STAGE = RT * F4_ROW;
-    constexpr int LD_ITERS = (F4_STAGE + NT - 1) / NT;
+    constexpr int PCAP = C::PCAP, NSUB = RT / 32;
+    constexpr int STAGE_BYTES = RT * LS * 4;
+    constexpr int NCHUNK = STAGE_BYTES / 1024;  // 1 KiB = one wave-wide 16-byte LDS-DMA load
+    constexpr int LD_ITERS = (NCHUNK + NW - 1) / NW;
+    constexpr int NORM_CHUNKS = RT / 64;        // 256 B = one wave-wide 4-byte LDS-DMA load
+    static_assert(STAGE_BYTES % 1024 == 0, "a stage is a whole number of wave-wide loads");
+    static_assert(RT % 64 == 0 && NORM_CHUNKS <= NW, "norms of a stage: one load per wave at most");
+    static_assert(NSUB % 2 == 0, "two accumulator sets alternate within a stage");
+    (void)ROWF;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* tile = reinterpret_cast<float*>(smem);           // [2][RT*LS]
     float* tnorm = tile + 2 * RT * LS;                      // [2][RT]
     uint2* pend = reinterpret_cast<uint2*>(tnorm + 2 * RT);  // [NW][32][PCAP]
     unsigned* cnt = reinterpret_cast<unsigned*>(pend + NW * 32 * PCAP);  // [NW][32]
+    const unsigned tile_lds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)tile;
+    const unsigned tnorm_lds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)tnorm;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -178,52 +234,47 @@ __global__ __launch_bounds__(FusedCfg<D2>::NW * 64, 2) void fused_knn_kernel(
     u64* lists_w = lists + ((long long)split * n_pad + q0) * 64;
 
     // B operand: this lane's query features, one register per MFMA step
-    float b[D2P];
+    float qf[D2P];
     {
         const float4* qp4 = reinterpret_cast<const float4*>(Qp + (q0 + j) * ROWF + hh * D2P);
 #pragma unroll
         for (int c = 0; c < D2P / 4; ++c) {
             float4 v = qp4[c];
-            b[4 * c + 0] = v.x; b[4 * c + 1] = v.y; b[4 * c + 2] = v.z; b[4 * c + 3] = v.w;
+            qf[4 * c + 0] = v.x; qf[4 * c + 1] = v.y; qf[4 * c + 2] = v.z; qf[4 * c + 3] = v.w;
         }
     }
+    // The loads above must be complete before the stage loop starts: a compiler-inserted
+    // wait for them inside the loop would also drain the LDS-DMA loads of the next stage.
+#pragma unroll
+    for (int c = 0; c < D2P; ++c) asm volatile("" : "+v"(qf[c]));
     // running threshold: score of the 64th best reference so far; padding queries take nothing
-    float tau = (q0 + j < n) ? __builtin_inff() : -__builtin_inff();
+    const float tau_max = __uint_as_float(TAU_MAX_BITS);  // padding rows score exactly this
+    float tau = (q0 + j < n && !(ablate & 1)) ? tau_max : -__builtin_inff();
     if (lane < 32) cnt_w[lane] = 0u;
     unsigned inited = 0u;  // bit q: query q's shortlist exists in global memory (wave-uniform)
 
-    // global -> register -> LDS staging of the next reference stage
-    float4 stg[LD_ITERS];
-    float4 stgn = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int i = 0; i < LD_ITERS; ++i) stg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-#define SCMIAC_ISSUE(T_)                                                                            \
+    // Stage copy global -> LDS without registers: RT packed rows are one contiguous byte
+    // range in both, and so are their norms.
+#define SCMIAC_STAGE(T_, BUF_)                                                                      \
     do {                                                                                            \
-        const float4* src_ =                                                                        \
-            reinterpret_cast<const float4*>(Rp + (r_begin + (long long)(T_) * RT) * ROWF);          \
+        const long long row0_ = r_begin + (long long)(T_) * RT;                                     \
+        const char* src_ = reinterpret_cast<const char*>(Rp + row0_ * LS);                          \
+        const unsigned dst_ = tile_lds + (unsigned)((BUF_) * STAGE_BYTES);                          \
         _Pragma("unroll") for (int i = 0; i < LD_ITERS; ++i) {                                      \
-            int e = tid + i * NT;                                                                   \
-            if (e < F4_STAGE) stg[i] = src_[e];                                                     \
+            const int ch = wave + i * NW; /* wave-uniform */                                        \
+            if (ch < NCHUNK) lds_dma_16(src_ + ch * 1024 + lane * 16, dst_ + ch * 1024);            \
         }                                                                                           \
-        if (tid < RT / 4)                                                                           \
-            stgn = reinterpret_cast<const float4*>(rnorm + r_begin + (long long)(T_) * RT)[tid];    \
-    } while (0)
-#define SCMIAC_COMMIT(BUF_)                                                                         \
-    do {                                                                                            \
-        float* tb_ = tile + (BUF_) * RT * LS;                                                       \
-        _Pragma("unroll") for (int i = 0; i < LD_ITERS; ++i) {                                      \
-            int e = tid + i * NT;                                                                   \
-            if (e < F4_STAGE) {                                                                     \
-                int row = e / F4_ROW, c4 = e - row * F4_ROW;                                        \
-                *reinterpret_cast<float4*>(tb_ + row * LS + c4 * 4) = stg[i];                       \
-            }                                                                                       \
-        }                                                                                           \
-        if (tid < RT / 4) reinterpret_cast<float4*>(tnorm + (BUF_) * RT)[tid] = stgn;               \
+        if (wave < NORM_CHUNKS)                                                                     \
+            lds_dma_4(rnorm + row0_ + wave * 64 + lane, tnorm_lds + (unsigned)(((BUF_) * RT + wave * 64) * 4)); \
     } while (0)
 
-    // flush every query of this wave whose pending count is >= min_cnt (or, at the end,
+    u64 dg_slow = 0, dg_flush = 0, dg_nslow = 0, dg_nflush = 0, dg_npush = 0, dg_iters = 0;
+    const u64 dg_t0 = diag ? (u64)clock64() : 0;
+
+    // merge every query of this wave whose pending count is >= min_cnt (or, at the end,
     // that has no shortlist in memory yet)
-    auto flush_full = [&](unsigned min_cnt, bool force_uninit) {
+    auto flush_full = [&](unsigned min_cnt, bool force_uninit) __attribute__((always_inline)) {
+        const u64 tf0 = diag ? (u64)clock64() : 0;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         unsigned c = cnt_w[j];
         bool need = (c >= min_cnt) || (force_uninit && !((inited >> j) & 1u) && (q0 + j < n));
@@ -236,86 +287,136 @@ __global__ __launch_bounds__(FusedCfg<D2>::NW * 64, 2) void fused_knn_kernel(
             float nt = flush_query(cq, pend_w + q * PCAP, lists_w + (long long)q * 64,
                                    (inited >> q) & 1u, lane);
             inited |= 1u << q;
-            if (j == q) tau = nt;
+            if (j == q) tau = fminf(nt, tau_max);
             if (lane == 0) cnt_w[q] = 0u;
+            if (diag) ++dg_nflush;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (diag) dg_flush += (u64)clock64() - tf0;
     };
 
-    if (T > 0) {
-        SCMIAC_ISSUE(0);
-        SCMIAC_COMMIT(0);
-    }
+    // Candidate path (entered when some lane's smallest key is below its threshold).
+    // Each lane walks its keys in ascending order: store the current one (one LDS atomic
+    // for the slot), then advance to the next greater key; a lane whose buffer is full
+    // waits for the merge and retries the same key against the new threshold.
+    auto select_slow = [&](const float (&key)[16], float kmin, unsigned ref0) __attribute__((always_inline)) {
+        const u64 ts0 = diag ? (u64)clock64() : 0;
+        if (diag) ++dg_nslow;
+        if (ablate & 8) {  // diagnostic: price of reaching this path and returning
+            if (diag) dg_slow += (u64)clock64() - ts0;
+            return;
+        }
+        __builtin_amdgcn_s_setprio(2);  // finish this short scalar/vector stretch ahead of the SIMD partner
+        float cur = kmin;
+        bool pass = cur < tau;
+        do {
+            if (diag) ++dg_iters;
+            unsigned slot = (unsigned)PCAP;
+            if (pass) slot = atomicAdd(&cnt_w[j], 1u);
+            // while the slot is on its way: this lane's next key in ascending order
+            float gt[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gt[r] = (key[r] > cur) ? key[r] : __builtin_inff();
+            float nxt = fminf(fminf(gt[0], gt[1]), gt[2]);
+#pragma unroll
+            for (int r = 3; r < 15; r += 2) nxt = fminf(fminf(nxt, gt[r]), gt[r + 1]);
+            nxt = fminf(nxt, gt[15]);
+            const bool stored = pass && slot < (unsigned)PCAP;
+            if (stored) {
+                const unsigned r = __float_as_uint(cur) & 15u;
+                pend_w[j * PCAP + slot] = make_uint2(__float_as_uint(cur), ref0 + (r & 3u) + 8u * (r >> 2));
+            }
+            if (diag) dg_npush += __popcll(__ballot(stored));
+            if (__any(pass && !stored)) {  // a buffer is full: merge, thresholds tighten
+                flush_full((unsigned)PCAP, false);
+            }
+            cur = stored ? nxt : cur;  // a lane that could not store retries the same key
+            pass = cur < tau;
+        } while (__any(pass));
+        __builtin_amdgcn_s_setprio(0);
+        if (diag) dg_slow += (u64)clock64() - ts0;
+    };
+
+    if (T > 0) SCMIAC_STAGE(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    for (int t = 0; t < T; ++t) {
-        if (t + 1 < T) SCMIAC_ISSUE(t + 1);
-        const float* tb = tile + (t & 1) * RT * LS;
-        const float* nb = tnorm + (t & 1) * RT;
+    // Software pipeline over subtiles (32 references each).  While the MFMA chain of
+    // subtile s runs, the wave issues the threshold test of subtile s-1 (other
+    // accumulator set) and the LDS reads of subtile s+1 (other fragment set).
+    constexpr int HEAD = D2 < 4 ? D2 : 4;  // MFMAs issued before the previous subtile's test
+    f32x16 accs[2];
+    float rfr[2][D2P];
+    unsigned ref0s[2] = {0u, 0u};
 #pragma unroll
-        for (int sub = 0; sub < NSUB; ++sub) {
-            // A operand: reference row (sub*32 + j), this lane half's features
-            float a[D2P];
-            const float4* ap = reinterpret_cast<const float4*>(tb + (sub * 32 + j) * LS + hh * D2P);
-#pragma unroll
-            for (int c = 0; c < D2P / 4; ++c) {
-                float4 v = ap[c];
-                a[4 * c + 0] = v.x; a[4 * c + 1] = v.y; a[4 * c + 2] = v.z; a[4 * c + 3] = v.w;
-            }
-            // accumulator starts at |r|^2 of the row each register holds
-            f32x16 acc;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float4 nv = *reinterpret_cast<const float4*>(nb + sub * 32 + 8 * g + 4 * hh);
-                acc[4 * g + 0] = nv.x; acc[4 * g + 1] = nv.y; acc[4 * g + 2] = nv.z; acc[4 * g + 3] = nv.w;
-            }
-#pragma unroll
-            for (int s = 0; s < D2; ++s)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+    for (int r = 0; r < 16; ++r) accs[1][r] = tau_max;  // "previous subtile" of the first one
 
-            // ---- selection: one compare per 16 pairs on the fast path ----------
-            float mn = fminf(fminf(acc[0], acc[1]), acc[2]);
+    const bool do_stage = !(ablate & 2);  // diagnostic: keep re-reading the first stage
+    const bool do_sync = !(ablate & 4);   // diagnostic: no block barrier (results are garbage)
+
+#define SCMIAC_LOAD_FRAGS(DST_, TB_, SUB_)                                                          \
+    do {                                                                                            \
+        const float* ap_ = (TB_) + ((SUB_) * 32 + j) * LS + hh * D2P;                               \
+        _Pragma("unroll") for (int c = 0; c < D2P / 4; ++c) {                                       \
+            float4 v = lds_read_b128(ap_ + 4 * c);                                                  \
+            (DST_)[4 * c + 0] = v.x; (DST_)[4 * c + 1] = v.y;                                       \
+            (DST_)[4 * c + 2] = v.z; (DST_)[4 * c + 3] = v.w;                                       \
+        }                                                                                           \
+    } while (0)
+// one subtile: CUR_/PRV_ are the compile-time indices of the two register sets
+#define SCMIAC_SUBTILE(CUR_, PRV_, SUB_)                                                            \
+    do {                                                                                            \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) { /* accumulator starts at |r|^2 */           \
+            float4 nv = lds_read_b128(nb + (SUB_) * 32 + 8 * g + 4 * hh);                           \
+            accs[CUR_][4 * g + 0] = nv.x; accs[CUR_][4 * g + 1] = nv.y;                             \
+            accs[CUR_][4 * g + 2] = nv.z; accs[CUR_][4 * g + 3] = nv.w;                             \
+        }                                                                                           \
+        _Pragma("unroll") for (int s = 0; s < HEAD; ++s)                                            \
+            accs[CUR_] = __builtin_amdgcn_mfma_f32_32x32x2f32(rfr[CUR_][s], qf[s], accs[CUR_], 0, 0, 0); \
+        if ((SUB_) + 1 < NSUB) SCMIAC_LOAD_FRAGS(rfr[PRV_], tb, (SUB_) + 1);                        \
+        float key_[16];                                                                             \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) key_[r] = score_key(accs[PRV_][r], r);       \
+        float mn_ = fminf(fminf(key_[0], key_[1]), key_[2]);                                        \
+        _Pragma("unroll") for (int r = 3; r < 15; r += 2) mn_ = fminf(fminf(mn_, key_[r]), key_[r + 1]); \
+        mn_ = fminf(mn_, key_[15]);                                                                 \
+        _Pragma("unroll") for (int s = HEAD; s < D2; ++s)                                           \
+            accs[CUR_] = __builtin_amdgcn_mfma_f32_32x32x2f32(rfr[CUR_][s], qf[s], accs[CUR_], 0, 0, 0); \
+        ref0s[CUR_] = (unsigned)(r_begin + (long long)t * RT + (SUB_) * 32 + 4 * hh);               \
+        if (__any(mn_ < tau)) select_slow(key_, mn_, ref0s[PRV_]);                                  \
+    } while (0)
+
+    for (int t = 0; t < T; ++t) {
+        if (do_stage && t + 1 < T) SCMIAC_STAGE(t + 1, (t + 1) & 1);
+        const float* tb = tile + (do_stage ? (t & 1) : 0) * RT * LS;
+        const float* nb = tnorm + (do_stage ? (t & 1) : 0) * RT;
+        // fragments of the stage's first subtile (the stage only became readable at the barrier)
+        SCMIAC_LOAD_FRAGS(rfr[0], tb, 0);
 #pragma unroll
-            for (int r = 3; r < 15; r += 2) mn = fminf(fminf(mn, acc[r]), acc[r + 1]);
-            mn = fminf(mn, acc[15]);
-            if (__any(mn < tau)) {
-                const unsigned ref0 = (unsigned)(r_begin + (long long)t * RT + sub * 32 + 4 * hh);
-                unsigned fail = 0u;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    if (acc[r] < tau) {
-                        unsigned slot = atomicAdd(&cnt_w[j], 1u);
-                        if (slot < (unsigned)PCAP)
-                            pend_w[j * PCAP + slot] =
-                                make_uint2(__float_as_uint(acc[r]), ref0 + (r & 3) + 8 * (r >> 2));
-                        else
-                            fail |= 1u << r;
-                    }
-                }
-                while (__any(fail != 0u)) {  // some query's buffer overflowed: merge, retry
-                    flush_full((unsigned)PCAP, false);
-                    unsigned f2 = 0u;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        if (((fail >> r) & 1u) && acc[r] < tau) {
-                            unsigned slot = atomicAdd(&cnt_w[j], 1u);
-                            if (slot < (unsigned)PCAP)
-                                pend_w[j * PCAP + slot] =
-                                    make_uint2(__float_as_uint(acc[r]), ref0 + (r & 3) + 8 * (r >> 2));
-                            else
-                                f2 |= 1u << r;
-                        }
-                    }
-                    fail = f2;
-                }
-            }
+        for (int sp = 0; sp < NSUB; sp += 2) {
+            SCMIAC_SUBTILE(0, 1, sp);
+            SCMIAC_SUBTILE(1, 0, sp + 1);
         }
-        if (t + 1 < T) SCMIAC_COMMIT((t + 1) & 1);
-        __syncthreads();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA loads have landed
+        if (do_sync) __syncthreads();
+    }
+    if (T > 0) {  // the last subtile is still untested
+        float key_[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) key_[r] = score_key(accs[1][r], r);
+        float mn_ = key_[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mn_ = fminf(mn_, key_[r]);
+        if (__any(mn_ < tau)) select_slow(key_, mn_, ref0s[1]);
     }
     flush_full(1u, true);
-#undef SCMIAC_ISSUE
-#undef SCMIAC_COMMIT
+    if (diag && lane == 0) {
+        u64* o = diag + ((long long)blockIdx.x * NW + wave) * 8;
+        o[0] = (u64)clock64() - dg_t0; o[1] = dg_slow; o[2] = dg_flush; o[3] = dg_nslow;
+        o[4] = dg_nflush; o[5] = dg_npush; o[6] = dg_iters; o[7] = 0;
+    }
+#undef SCMIAC_STAGE
+#undef SCMIAC_LOAD_FRAGS
+#undef SCMIAC_SUBTILE
 }
 
 // --------------------------------------------------------------------------------
@@ -512,19 +613,31 @@ int knn_pick_d2(int d) {
     return -1;
 }
 
-template <int D2>
+template <int D2, int NW, int RT>
 static hipError_t launch_fused_t(const float* Qp, const float* Rp, const float* rnorm, u64* lists,
                                  long long n, long long n_pad, int nqb, int S, long long chunk_rows,
-                                 hipStream_t stream) {
-    using C = FusedCfg<D2>;
+                                 u64* diag, hipStream_t stream) {
+    using C = FusedCfg<D2, NW, RT>;
     size_t lds = C::lds_bytes();
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_knn_kernel<D2>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_knn_kernel<D2, NW, RT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    dim3 grid((unsigned)(nqb * S)), block(C::NW * 64);
-    hipLaunchKernelGGL(fused_knn_kernel<D2>, grid, block, lds, stream, Qp, Rp, rnorm, lists, n, n_pad,
-                       nqb, chunk_rows);
+    dim3 grid((unsigned)(nqb * S)), block(NW * 64);
+    int ablate = 0;
+    if (const char* v = getenv("SCMIAC_FUSED_ABLATE")) ablate = atoi(v);  // diagnostic builds only
+    hipLaunchKernelGGL((fused_knn_kernel<D2, NW, RT>), grid, block, lds, stream, Qp, Rp, rnorm, lists, n,
+                       n_pad, nqb, chunk_rows, ablate, diag);
     return hipGetLastError();
+}
+
+// (waves per block, reference rows per LDS stage) of the fused kernel
+static void fused_variant(int D2, int* nw, int* rt) {
+    *nw = 8;
+    *rt = (D2 <= 32) ? 128 : 64;
+    if (const char* v = getenv("SCMIAC_FUSED_VARIANT")) {  // tuning aid: "NWxRT", e.g. 4x64
+        int a = 0, b = 0;
+        if (sscanf(v, "%dx%d", &a, &b) == 2 && D2 == 25) { *nw = a; *rt = b; }
+    }
 }
 
 KnnGeometry knn_geometry(long long n, long long m, int d, int splits) {
@@ -533,8 +646,9 @@ KnnGeometry knn_geometry(long long n, long long m, int d, int splits) {
     if (g.D2 < 0) return g;
     g.D2P = (g.D2 + 3) & ~3;
     g.rowf = 2 * g.D2P;
-    g.RT = (g.D2 <= 32) ? 128 : 64;
-    g.qpb = 256;
+    g.ls = g.rowf + (((g.rowf / 4) % 2 == 0) ? 4 : 8);
+    fused_variant(g.D2, &g.nw, &g.RT);
+    g.qpb = g.nw * 32;
     g.n_pad = ((n + g.qpb - 1) / g.qpb) * g.qpb;
     g.nqb = (int)(g.n_pad / g.qpb);
     int S = splits;
@@ -558,31 +672,32 @@ KnnGeometry knn_geometry(long long n, long long m, int d, int splits) {
 }
 
 hipError_t launch_pack(const float* X, long long n, int d, const KnnGeometry& g, float scale, float* Xp,
-                       float* norms, long long n_pad, unsigned* maxnorm_bits, hipStream_t stream) {
+                       int ld, float* norms, long long n_pad, unsigned* maxnorm_bits, hipStream_t stream) {
     dim3 block(256), grid((unsigned)((n_pad + 255) / 256));
-    hipLaunchKernelGGL(pack_rows_kernel, grid, block, 0, stream, X, n, d, g.D2, g.D2P, scale, Xp, norms,
+    hipLaunchKernelGGL(pack_rows_kernel, grid, block, 0, stream, X, n, d, g.D2, g.D2P, scale, Xp, ld, norms,
                        n_pad, maxnorm_bits);
     return hipGetLastError();
 }
 
 hipError_t launch_fused(const KnnGeometry& g, const float* Qp, const float* Rp, const float* rnorm,
-                        unsigned long long* lists, long long n, hipStream_t stream) {
-#define SCMIAC_FUSED_CASE(V)                                                                  \
-    case V:                                                                                   \
-        return launch_fused_t<V>(Qp, Rp, rnorm, lists, n, g.n_pad, g.nqb, g.S, g.chunk_rows, stream);
-    switch (g.D2) {
-        SCMIAC_FUSED_CASE(8)
-        SCMIAC_FUSED_CASE(15)
-        SCMIAC_FUSED_CASE(16)
-        SCMIAC_FUSED_CASE(20)
-        SCMIAC_FUSED_CASE(25)
-        SCMIAC_FUSED_CASE(32)
-        SCMIAC_FUSED_CASE(40)
-        SCMIAC_FUSED_CASE(50)
-        SCMIAC_FUSED_CASE(64)
-        default:
-            return hipErrorInvalidValue;
-    }
+                        unsigned long long* lists, long long n, unsigned long long* diag,
+                        hipStream_t stream) {
+#define SCMIAC_FUSED_CASE(V_, NW_, RT_)                                                            \
+    if (g.D2 == V_ && g.nw == NW_ && g.RT == RT_)                                                  \
+        return launch_fused_t<V_, NW_, RT_>(Qp, Rp, rnorm, lists, n, g.n_pad, g.nqb, g.S, g.chunk_rows, diag, stream);
+    SCMIAC_FUSED_CASE(8, 8, 128)
+    SCMIAC_FUSED_CASE(15, 8, 128)
+    SCMIAC_FUSED_CASE(16, 8, 128)
+    SCMIAC_FUSED_CASE(20, 8, 128)
+    SCMIAC_FUSED_CASE(25, 8, 128)
+    SCMIAC_FUSED_CASE(32, 8, 128)
+    SCMIAC_FUSED_CASE(40, 8, 64)
+    SCMIAC_FUSED_CASE(50, 8, 64)
+    SCMIAC_FUSED_CASE(64, 8, 64)
+    SCMIAC_FUSED_CASE(25, 4, 64)
+    SCMIAC_FUSED_CASE(25, 4, 128)
+    SCMIAC_FUSED_CASE(25, 2, 64)
+    return hipErrorInvalidValue;
 #undef SCMIAC_FUSED_CASE
 }
 
@@ -595,7 +710,8 @@ hipError_t launch_refine(const float* Q, const float* R, int d, long long n, con
     //   D >= T (1 - gamma_{d+2})
     // both taken with a factor-two margin.
     const double u = 5.9604644775390625e-08;  // 2^-24
-    double G = 2.0 * (double)(d + 2 * g.D2 + 4) * u;
+    // + 32 u: the selection key replaces the low four mantissa bits of the score
+    double G = 2.0 * (double)(d + 2 * g.D2 + 4 + 32) * u;
     double err_abs_coef = 2.0 * G;
     double rel_keep = 1.0 - 2.0 * (double)(d + 4) * u;
     dim3 block(256), grid((unsigned)((n + 3) / 4));
