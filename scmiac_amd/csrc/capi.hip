@@ -140,13 +140,13 @@ int scmiac_knn_search(const float* q, int64_t n, const float* r, int64_t m, int 
         HIP_TRY(hipEventRecord(g_ev0[g_ev_used], stream), "event record");
     }
     const char* dg = getenv("SCMIAC_FUSED_DIAG");  // diagnostic runs: per-wave cycle counters
-    HIP_TRY(launch_fused(g, w.qp, w.rp, w.rnorm, w.lists, n, (dg && dg[0] == '1') ? w.diag : nullptr, stream),
+    HIP_TRY(launch_fused(g, w.qp, w.rp, w.rnorm, w.lists, n, knn_threshold_rank(k), (dg && dg[0] == '1') ? w.diag : nullptr, stream),
             "fused distance + top-k");
     if (timed) {
         HIP_TRY(hipEventRecord(g_ev1[g_ev_used], stream), "event record");
         ++g_ev_used;
     }
-    HIP_TRY(launch_refine(q, r, d, n, g, w.lists, k, col_offset, merge, w.maxnorm, idx, dist2, dist,
+    HIP_TRY(launch_refine(q, r, d, n, g, w.lists, k, knn_threshold_rank(k), col_offset, merge, w.maxnorm, idx, dist2, dist,
                           lower_bound, uncertified_rows, n_uncertified, stream),
             "refine");
     if (exact_fallback)

@@ -27,15 +27,18 @@ struct KnnGeometry {
 };
 
 int knn_pick_d2(int d);
+// rank of the shortlist entry whose key serves as the running threshold: the k wanted
+// neighbours plus a margin that the rounding-error certificate can absorb
+inline int knn_threshold_rank(int k) { return (k + 6 < 64) ? k + 6 : 64; }
 KnnGeometry knn_geometry(long long n, long long m, int d, int splits);
 
 hipError_t launch_pack(const float* X, long long n, int d, const KnnGeometry& g, float scale, float* Xp,
                        int ld, float* norms, long long n_pad, unsigned* maxnorm_bits, hipStream_t stream);
 hipError_t launch_fused(const KnnGeometry& g, const float* Qp, const float* Rp, const float* rnorm,
-                        unsigned long long* lists, long long n, unsigned long long* diag,
+                        unsigned long long* lists, long long n, int kt, unsigned long long* diag,
                         hipStream_t stream);
 hipError_t launch_refine(const float* Q, const float* R, int d, long long n, const KnnGeometry& g,
-                         const unsigned long long* lists, int k, long long col_offset, int merge,
+                         const unsigned long long* lists, int k, int kt, long long col_offset, int merge,
                          const unsigned* maxnorm_bits, int* idx, float* d2, float* dist, double* lb,
                          int* fail_rows, int* n_fail, hipStream_t stream);
 hipError_t launch_exact_rows(const float* Q, const float* R, int d, long long n, long long m, int k,

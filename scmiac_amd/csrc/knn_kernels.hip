@@ -173,9 +173,9 @@ __device__ __forceinline__ float4 lds_read_b128(const float* p) {
 }
 
 // Merge query q's pending candidates into its 64-entry shortlist (global memory),
-// all 64 lanes cooperating.  Returns the new threshold (score of the 64th entry).
+// all 64 lanes cooperating.  Returns the new threshold (key of the kt-th entry).
 __device__ __forceinline__ float flush_query(unsigned c, const uint2* pend_q, u64* list_q,
-                                             bool inited, int lane) {
+                                             bool inited, int lane, int kt) {
     u64 key = LIST_SENTINEL;
     if ((unsigned)lane < c) {
         uint2 e = pend_q[lane];
@@ -188,7 +188,9 @@ __device__ __forceinline__ float flush_query(unsigned c, const uint2* pend_q, u6
     key = umin64(key, old);  // the 64 smallest of the union, as a bitonic sequence
     key = wave_merge(key, lane);
     list_q[lane] = key;
-    unsigned top = __builtin_amdgcn_readlane((unsigned)(key >> 32), 63);
+    // the threshold is the kt-th smallest key, not the 64th: fewer candidates pass, and
+    // everything outside the 64-entry list still scores at least this much
+    unsigned top = __builtin_amdgcn_readlane((unsigned)(key >> 32), kt - 1);
     return ord2f(top);
 }
 
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(NW_ * 64, 2) void fused_knn_kernel(
     const float* __restrict__ Rp,     // [m_pad][LS], zero pad columns
     const float* __restrict__ rnorm,  // [m_pad], 1.7e38 on padding rows
     u64* __restrict__ lists,          // [S][n_pad][64]
-    long long n, long long n_pad, int nqb, long long chunk_rows, int ablate,
+    long long n, long long n_pad, int nqb, long long chunk_rows, int kt, int ablate,
     u64* __restrict__ diag /* per wave 8 counters, or NULL (diagnostic runs only) */) {
     using C = FusedCfg<D2, NW_, RT_>;
     constexpr int D2P = C::D2P, ROWF = C::ROWF, LS = C::LS, RT = C::RT, NW = C::NW;
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(NW_ * 64, 2) void fused_knn_kernel(
             unsigned cq = __builtin_amdgcn_readlane(c, q);
             cq = cq > (unsigned)PCAP ? (unsigned)PCAP : cq;
             float nt = flush_query(cq, pend_w + q * PCAP, lists_w + (long long)q * 64,
-                                   (inited >> q) & 1u, lane);
+                                   (inited >> q) & 1u, lane, kt);
             inited |= 1u << q;
             if (j == q) tau = fminf(nt, tau_max);
             if (lane == 0) cnt_w[q] = 0u;
@@ -435,7 +437,7 @@ __device__ __forceinline__ float exact_dist2(const float* __restrict__ a, const 
 
 __global__ __launch_bounds__(256) void refine_kernel(
     const float* __restrict__ Q, const float* __restrict__ R, int d, long long n, long long n_pad,
-    const u64* __restrict__ lists, int S, int k, long long col_offset, int merge,
+    const u64* __restrict__ lists, int S, int k, int kt, long long col_offset, int merge,
     double err_abs_coef,  // 2*G: |s + |q|^2 - T| <= err_abs_coef * (|r|^2 + |q|^2)
     double rel_keep,      // 1 - gamma: D >= T * rel_keep
     const unsigned* __restrict__ maxnorm_bits, int* __restrict__ out_idx,
@@ -463,7 +465,7 @@ __global__ __launch_bounds__(256) void refine_kernel(
     for (int s = 0; s < S; ++s) {
         u64 e = lists[((long long)s * n_pad + q) * 64 + lane];
         unsigned ridx = (unsigned)e;
-        float tau_s = ord2f(__builtin_amdgcn_readlane((unsigned)(e >> 32), 63));
+        float tau_s = ord2f(__builtin_amdgcn_readlane((unsigned)(e >> 32), kt - 1));
         u64 key = KEY_SENTINEL;
         if (ridx != 0xffffffffu) {
             float D = exact_dist2(qrow, R + (long long)ridx * d, d);
@@ -616,7 +618,7 @@ int knn_pick_d2(int d) {
 template <int D2, int NW, int RT>
 static hipError_t launch_fused_t(const float* Qp, const float* Rp, const float* rnorm, u64* lists,
                                  long long n, long long n_pad, int nqb, int S, long long chunk_rows,
-                                 u64* diag, hipStream_t stream) {
+                                 int kt, u64* diag, hipStream_t stream) {
     using C = FusedCfg<D2, NW, RT>;
     size_t lds = C::lds_bytes();
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_knn_kernel<D2, NW, RT>),
@@ -626,7 +628,7 @@ static hipError_t launch_fused_t(const float* Qp, const float* Rp, const float* 
     int ablate = 0;
     if (const char* v = getenv("SCMIAC_FUSED_ABLATE")) ablate = atoi(v);  // diagnostic builds only
     hipLaunchKernelGGL((fused_knn_kernel<D2, NW, RT>), grid, block, lds, stream, Qp, Rp, rnorm, lists, n,
-                       n_pad, nqb, chunk_rows, ablate, diag);
+                       n_pad, nqb, chunk_rows, kt, ablate, diag);
     return hipGetLastError();
 }
 
@@ -680,11 +682,11 @@ hipError_t launch_pack(const float* X, long long n, int d, const KnnGeometry& g,
 }
 
 hipError_t launch_fused(const KnnGeometry& g, const float* Qp, const float* Rp, const float* rnorm,
-                        unsigned long long* lists, long long n, unsigned long long* diag,
+                        unsigned long long* lists, long long n, int kt, unsigned long long* diag,
                         hipStream_t stream) {
 #define SCMIAC_FUSED_CASE(V_, NW_, RT_)                                                            \
     if (g.D2 == V_ && g.nw == NW_ && g.RT == RT_)                                                  \
-        return launch_fused_t<V_, NW_, RT_>(Qp, Rp, rnorm, lists, n, g.n_pad, g.nqb, g.S, g.chunk_rows, diag, stream);
+        return launch_fused_t<V_, NW_, RT_>(Qp, Rp, rnorm, lists, n, g.n_pad, g.nqb, g.S, g.chunk_rows, kt, diag, stream);
     SCMIAC_FUSED_CASE(8, 8, 128)
     SCMIAC_FUSED_CASE(15, 8, 128)
     SCMIAC_FUSED_CASE(16, 8, 128)
@@ -702,7 +704,7 @@ hipError_t launch_fused(const KnnGeometry& g, const float* Qp, const float* Rp, 
 }
 
 hipError_t launch_refine(const float* Q, const float* R, int d, long long n, const KnnGeometry& g,
-                         const unsigned long long* lists, int k, long long col_offset, int merge,
+                         const unsigned long long* lists, int k, int kt, long long col_offset, int merge,
                          const unsigned* maxnorm_bits, int* idx, float* d2, float* dist, double* lb,
                          int* fail_rows, int* n_fail, hipStream_t stream) {
     // rounding-error model of the fused score (see the derivation in DESIGN.md):
@@ -715,7 +717,7 @@ hipError_t launch_refine(const float* Q, const float* R, int d, long long n, con
     double err_abs_coef = 2.0 * G;
     double rel_keep = 1.0 - 2.0 * (double)(d + 4) * u;
     dim3 block(256), grid((unsigned)((n + 3) / 4));
-    hipLaunchKernelGGL(refine_kernel, grid, block, 0, stream, Q, R, d, n, g.n_pad, lists, g.S, k,
+    hipLaunchKernelGGL(refine_kernel, grid, block, 0, stream, Q, R, d, n, g.n_pad, lists, g.S, k, kt,
                        col_offset, merge, err_abs_coef, rel_keep, maxnorm_bits, idx, d2, dist, lb,
                        fail_rows, n_fail);
     return hipGetLastError();
