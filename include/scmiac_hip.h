@@ -91,11 +91,14 @@ SCMIAC_API int scmiac_knn_search(const float *q, int64_t n, const float *r, int6
  * reference block `r` into idx/dist2 (which must already hold k valid-or-padded
  * entries per row, e.g. from scmiac_knn_search).  `rows` [*n_rows] int32 and
  * n_rows [1] int32 live on the device.  Same ordering rule as scmiac_knn_search;
- * same reference call sites.
+ * same reference call sites.  `workspace` is optional device scratch (NULL: none):
+ * with 128 KiB per listed row (up to 4096 rows) each row's scan of `r` is spread
+ * over the whole GPU instead of one compute unit; the result is the same.
  */
 SCMIAC_API int scmiac_knn_exact_rows(const float *q, int64_t n, const float *r, int64_t m, int d, int k,
                           int64_t col_offset, const int32_t *rows, const int32_t *n_rows,
-                          int32_t *idx, float *dist2, float *dist, void *stream);
+                          int32_t *idx, float *dist2, float *dist, void *workspace,
+                          size_t workspace_bytes, void *stream);
 
 /*
  * Mutual-nearest-neighbour anchors -- scmiac/preprocessing/anchors.py:569-572

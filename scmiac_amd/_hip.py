@@ -28,7 +28,7 @@ _SIGNATURES = {
     "scmiac_knn_workspace_size": ([_i64, _i64, _i32, _i32, _i32, _c.POINTER(_sz)], _c.c_int),
     "scmiac_knn_search": ([_vp, _i64, _vp, _i64, _i32, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp,
                            _vp, _i32, _vp, _sz, _vp], _c.c_int),
-    "scmiac_knn_exact_rows": ([_vp, _i64, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
+    "scmiac_knn_exact_rows": ([_vp, _i64, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
                               _c.c_int),
     "scmiac_find_mnn": ([_vp, _i64, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _sz, _vp], _c.c_int),
     "scmiac_compact_workspace_size": ([_i64, _c.POINTER(_sz)], _c.c_int),
@@ -156,15 +156,20 @@ def knn_search(q, r, k, *, col_offset=0, state=None, splits=0, exact_fallback=Tr
     return state
 
 
-def knn_exact_rows(q, r, k, rows, n_rows, state, *, col_offset=0):
+def knn_exact_rows(q, r, k, rows, n_rows, state, *, col_offset=0, scratch_rows=64):
+    """Direct-evaluation merge of reference block ``r`` into ``state`` for the listed rows.
+    ``scratch_rows`` listed rows get 128 KiB of scratch each and are scanned GPU-wide."""
     lib = require_gpu()
     device = state.idx.device
     q = _dev_f32(q, device)
     r = _dev_f32(r, device)
+    nbytes = int(scratch_rows) * 128 * 1024
+    ws = _workspace(nbytes, device) if nbytes else None
     with torch.cuda.device(device):
         _check(lib.scmiac_knn_exact_rows(_ptr(q), q.shape[0], _ptr(r), r.shape[0], q.shape[1], k, col_offset,
                                          _ptr(rows), _ptr(n_rows), _ptr(state.idx), _ptr(state.dist2),
-                                         _ptr(state.dist), _stream()))
+                                         _ptr(state.dist), _ptr(ws) if ws is not None else None, nbytes,
+                                         _stream()))
     return state
 
 

@@ -52,12 +52,12 @@ static KnnWs knn_carve(void* ws, long long n, const KnnGeometry& g) {
     w.rnorm = reinterpret_cast<float*>(p + off);
     off += up256(sizeof(float) * (size_t)g.m_pad);
     w.lists = reinterpret_cast<unsigned long long*>(p + off);
-    off += up256(sizeof(unsigned long long) * (size_t)g.S * g.n_pad * 64);
+    off += up256(sizeof(unsigned long long) * (size_t)g.list_rows * 64);
     w.maxnorm = reinterpret_cast<unsigned*>(p + off);
     off += 256;
     w.diag = reinterpret_cast<unsigned long long*>(p + off);
     w.diag_offset = off;
-    w.diag_bytes = sizeof(unsigned long long) * 8 * (size_t)g.nqb * g.S * g.nw;
+    w.diag_bytes = sizeof(unsigned long long) * 8 * (size_t)g.blocks * g.nw;
     off += up256(w.diag_bytes);
     w.total = off;
     return w;
@@ -104,7 +104,7 @@ int scmiac_knn_diag_region(int64_t n, int64_t m, int d, int k, int splits, size_
     KnnWs w = knn_carve(nullptr, n, g);
     *offset = w.diag_offset;
     *bytes = w.diag_bytes;
-    *waves = g.nqb * g.S * g.nw;
+    *waves = g.blocks * g.nw;
     return SCMIAC_OK;
 }
 
@@ -149,23 +149,23 @@ int scmiac_knn_search(const float* q, int64_t n, const float* r, int64_t m, int 
     HIP_TRY(launch_refine(q, r, d, n, g, w.lists, k, knn_threshold_rank(k), col_offset, merge, w.maxnorm, idx, dist2, dist,
                           lower_bound, uncertified_rows, n_uncertified, stream),
             "refine");
-    if (exact_fallback)
+    if (exact_fallback)  // the shortlists are dead once refine has run: their memory is the scratch
         HIP_TRY(launch_exact_rows(q, r, d, n, m, k, col_offset, uncertified_rows, n_uncertified, idx, dist2,
-                                  dist, stream),
+                                  dist, w.lists, sizeof(unsigned long long) * (size_t)g.list_rows * 64, stream),
                 "exact rows");
     return SCMIAC_OK;
 }
 
 int scmiac_knn_exact_rows(const float* q, int64_t n, const float* r, int64_t m, int d, int k,
                           int64_t col_offset, const int32_t* rows, const int32_t* n_rows, int32_t* idx,
-                          float* dist2, float* dist, void* stream_) {
+                          float* dist2, float* dist, void* workspace, size_t workspace_bytes, void* stream_) {
     int rc = check_knn_args(n, m, d, k);
     if (rc) return rc;
     if (n == 0) return SCMIAC_OK;
     if (!q || !rows || !n_rows || !idx || !dist2) return fail(SCMIAC_ERR_ARG, "NULL device pointer");
     if (m > 0 && !r) return fail(SCMIAC_ERR_ARG, "NULL reference pointer");
-    HIP_TRY(launch_exact_rows(q, r, d, n, m, k, col_offset, rows, n_rows, idx, dist2, dist,
-                              static_cast<hipStream_t>(stream_)),
+    HIP_TRY(launch_exact_rows(q, r, d, n, m, k, col_offset, rows, n_rows, idx, dist2, dist, workspace,
+                              workspace ? workspace_bytes : 0, static_cast<hipStream_t>(stream_)),
             "exact rows");
     return SCMIAC_OK;
 }

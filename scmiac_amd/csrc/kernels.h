@@ -11,6 +11,19 @@ namespace scmiac {
 
 // Shapes derived from (n, m, d, splits): padded row counts, packed row length and
 // how the reference rows are cut into independently searched chunks.
+// The query blocks of the grid's last, partly filled round ("tail") search the
+// references in St chunks each; everything before them is one block per (chunk, query block).
+struct FusedTail {
+    int qb0;               // first query block of the tail (== nqb when there is none)
+    int St;                // reference chunks per tail query block (1: no tail)
+    int block0;            // first grid block of the tail
+    int qpb;               // queries per block
+    long long chunk_rows;  // rows per tail chunk (multiple of RT)
+    long long m_pad;       // padded reference rows
+    long long rows;        // query rows in the tail
+    long long lists_row0;  // first shortlist row of the tail's chunks 1..St-1
+};
+
 struct KnnGeometry {
     int D2;                // MFMA K steps per tile (two features per step)
     int D2P;               // D2 rounded up to a multiple of 4
@@ -24,6 +37,9 @@ struct KnnGeometry {
     long long n_pad;       // queries padded to a multiple of qpb
     long long chunk_rows;  // rows per chunk (multiple of RT)
     long long m_pad;       // S * chunk_rows
+    FusedTail tail;
+    long long list_rows;   // 64-entry shortlists in the workspace
+    int blocks;            // grid size of the fused kernel
 };
 
 int knn_pick_d2(int d);
@@ -43,7 +59,8 @@ hipError_t launch_refine(const float* Q, const float* R, int d, long long n, con
                          int* fail_rows, int* n_fail, hipStream_t stream);
 hipError_t launch_exact_rows(const float* Q, const float* R, int d, long long n, long long m, int k,
                              long long col_offset, const int* rows, const int* n_rows, int* idx,
-                             float* d2, float* dist, hipStream_t stream);
+                             float* d2, float* dist, void* scratch, size_t scratch_bytes,
+                             hipStream_t stream);
 
 // graph kernels (mutual nearest neighbours, shared-neighbour score, label filter)
 size_t compact_workspace_bytes(long long n_items);

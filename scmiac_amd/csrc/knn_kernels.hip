@@ -199,8 +199,8 @@ __global__ __launch_bounds__(NW_ * 64, 2) void fused_knn_kernel(
     const float* __restrict__ Qp,     // [n_pad][ROWF], already scaled by -2
     const float* __restrict__ Rp,     // [m_pad][LS], zero pad columns
     const float* __restrict__ rnorm,  // [m_pad], 1.7e38 on padding rows
-    u64* __restrict__ lists,          // [S][n_pad][64]
-    long long n, long long n_pad, int nqb, long long chunk_rows, int kt, int ablate,
+    u64* __restrict__ lists,          // [S][n_pad][64], then the tail region's extra lists
+    long long n, long long n_pad, int nqb, long long chunk_rows, FusedTail tail, int kt, int ablate,
     u64* __restrict__ diag /* per wave 8 counters, or NULL (diagnostic runs only) */) {
     using C = FusedCfg<D2, NW_, RT_>;
     constexpr int D2P = C::D2P, ROWF = C::ROWF, LS = C::LS, RT = C::RT, NW = C::NW;
@@ -226,14 +226,33 @@ __global__ __launch_bounds__(NW_ * 64, 2) void fused_knn_kernel(
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, hh = lane >> 5;
-    const int split = blockIdx.x / nqb, qb = blockIdx.x % nqb;
+    // Blocks below tail.block0 search reference chunk `split` of query block `qb`; the
+    // blocks from tail.block0 on belong to the last, partly filled round of the grid and
+    // cut their query blocks' reference range into tail.St shorter chunks instead.
+    int split, qb;
+    long long r_begin, rows_here;
+    long long list_row;  // row of the [.][64] shortlist array this wave's first query uses
+    if ((int)blockIdx.x < tail.block0) {
+        split = blockIdx.x / nqb; qb = blockIdx.x % nqb;
+        r_begin = (long long)split * chunk_rows;
+        rows_here = chunk_rows;
+        list_row = (long long)split * n_pad + (long long)qb * C::QPB + wave * 32;
+    } else {
+        const int tb = (int)blockIdx.x - tail.block0;
+        split = tb % tail.St; qb = tail.qb0 + tb / tail.St;
+        r_begin = (long long)split * tail.chunk_rows;
+        rows_here = tail.m_pad - r_begin;
+        rows_here = rows_here < 0 ? 0 : (rows_here < tail.chunk_rows ? rows_here : tail.chunk_rows);
+        const long long qrow = (long long)qb * C::QPB + wave * 32;
+        list_row = split == 0 ? qrow
+                              : tail.lists_row0 + (long long)(split - 1) * tail.rows + (qrow - (long long)tail.qb0 * C::QPB);
+    }
     const long long q0 = (long long)qb * C::QPB + wave * 32;  // first query of this wave
-    const long long r_begin = (long long)split * chunk_rows;
-    const int T = (int)(chunk_rows / RT);
+    const int T = (int)(rows_here / RT);
 
     uint2* pend_w = pend + wave * 32 * PCAP;
     unsigned* cnt_w = cnt + wave * 32;
-    u64* lists_w = lists + ((long long)split * n_pad + q0) * 64;
+    u64* lists_w = lists + list_row * 64;
 
     // B operand: this lane's query features, one register per MFMA step
     float qf[D2P];
@@ -437,7 +456,7 @@ __device__ __forceinline__ float exact_dist2(const float* __restrict__ a, const 
 
 __global__ __launch_bounds__(256) void refine_kernel(
     const float* __restrict__ Q, const float* __restrict__ R, int d, long long n, long long n_pad,
-    const u64* __restrict__ lists, int S, int k, int kt, long long col_offset, int merge,
+    const u64* __restrict__ lists, int S, FusedTail tail, int k, int kt, long long col_offset, int merge,
     double err_abs_coef,  // 2*G: |s + |q|^2 - T| <= err_abs_coef * (|r|^2 + |q|^2)
     double rel_keep,      // 1 - gamma: D >= T * rel_keep
     const unsigned* __restrict__ maxnorm_bits, int* __restrict__ out_idx,
@@ -462,8 +481,13 @@ __global__ __launch_bounds__(256) void refine_kernel(
         }
         lb = lower_bound[q];
     }
-    for (int s = 0; s < S; ++s) {
-        u64 e = lists[((long long)s * n_pad + q) * 64 + lane];
+    const long long tail_q0 = (long long)tail.qb0 * tail.qpb;
+    const bool in_tail = tail.St > 1 && q >= tail_q0;
+    const int S_q = in_tail ? tail.St : S;
+    for (int s = 0; s < S_q; ++s) {
+        long long lrow = (long long)s * n_pad + q;
+        if (in_tail && s > 0) lrow = tail.lists_row0 + (long long)(s - 1) * tail.rows + (q - tail_q0);
+        u64 e = lists[lrow * 64 + lane];
         unsigned ridx = (unsigned)e;
         float tau_s = ord2f(__builtin_amdgcn_readlane((unsigned)(e >> 32), kt - 1));
         u64 key = KEY_SENTINEL;
@@ -504,10 +528,17 @@ __global__ __launch_bounds__(256) void refine_kernel(
 
 // --------------------------------------------------------------------------------
 // exact_rows: direct evaluation against every reference row for the listed queries;
-// merges into idx/dist2 (top-k of the union).  One 256-thread block per listed row.
+// merges into idx/dist2 (top-k of the union).
+//   MODE 0  one 256-thread block per listed row streams all m references.
+//   MODE 1  block (chunk, row): exact top-k of one reference chunk among the keys not
+//           above the row's current k-th key -> parts[row][chunk][0..k)
+//   MODE 2  one block per listed row merges its nch partial lists with the prior result.
+// Modes 1+2 serve the first `row_limit` listed rows (a handful of rows then use the
+// whole GPU instead of one CU each); MODE 0 serves the rows from `first_row` on.
 // --------------------------------------------------------------------------------
 static constexpr int EX_CAP = 2048;
 static constexpr int EX_NT = 256;
+static constexpr int EX_PART_STRIDE = 64;  // keys reserved per (row, chunk) partial list
 
 __device__ void block_bitonic_sort(u64* v, int n_pow2, int tid) {
     for (int k = 2; k <= n_pow2; k <<= 1) {
@@ -525,45 +556,70 @@ __device__ void block_bitonic_sort(u64* v, int n_pow2, int tid) {
     }
 }
 
+template <int MODE>
 __global__ __launch_bounds__(EX_NT) void exact_rows_kernel(
     const float* __restrict__ Q, const float* __restrict__ R, int d, long long m, int k,
     long long col_offset, const int* __restrict__ rows, const int* __restrict__ n_rows,
-    int* __restrict__ idx_io, float* __restrict__ d2_io, float* __restrict__ dist_out) {
+    int* __restrict__ idx_io, float* __restrict__ d2_io, float* __restrict__ dist_out,
+    u64* __restrict__ parts, int nch, long long chunk_len, int first_row, int row_limit) {
     __shared__ u64 cand[EX_CAP];
     __shared__ u64 prior[SCMIAC_KNN_MAX_K_INTERNAL];
     __shared__ float qs[SCMIAC_KNN_MAX_D_INTERNAL];
     __shared__ unsigned cnt;
     __shared__ u64 thr;
     const int tid = threadIdx.x;
-    const int total = *n_rows;
-    for (int f = blockIdx.x; f < total; f += gridDim.x) {
+    int total = *n_rows;
+    int f0, fstep;
+    if (MODE == 0) {
+        f0 = first_row + (int)blockIdx.x; fstep = (int)gridDim.x;
+    } else {
+        total = total < row_limit ? total : row_limit;
+        f0 = (MODE == 1) ? (int)blockIdx.y : (int)blockIdx.x;
+        fstep = (MODE == 1) ? (int)gridDim.y : (int)gridDim.x;
+    }
+    // the stream of keys this block looks at: reference rows [x_begin, x_end) (modes 0, 1)
+    // or the nch * k partial keys of the row (mode 2)
+    long long x_begin = 0, x_end = m;
+    if (MODE == 1) {
+        x_begin = (long long)blockIdx.x * chunk_len;
+        x_end = x_begin + chunk_len < m ? x_begin + chunk_len : m;
+    }
+    if (MODE == 2) x_end = (long long)nch * k;
+    for (int f = f0; f < total; f += fstep) {
         const long long q = rows[f];
         __syncthreads();
-        for (int i = tid; i < d; i += EX_NT) qs[i] = Q[q * d + i];
+        if (MODE != 2)
+            for (int i = tid; i < d; i += EX_NT) qs[i] = Q[q * d + i];
         if (tid < k) {
             int pi = idx_io[q * k + tid];
             u64 key = pi >= 0 ? (((u64)__float_as_uint(d2_io[q * k + tid]) << 32) | (u64)(unsigned)pi)
                               : KEY_SENTINEL;
             prior[tid] = key;
-            cand[tid] = key;
+            if (MODE != 1) cand[tid] = key;
         }
         __syncthreads();
         if (tid == 0) {
             int nv = 0;
             while (nv < k && prior[nv] != KEY_SENTINEL) ++nv;
             // prior rows are sorted ascending: compact form, valid entries first
-            cnt = (unsigned)nv;
+            cnt = (MODE == 1) ? 0u : (unsigned)nv;
             thr = (nv == k) ? prior[k - 1] : (KEY_SENTINEL - 1);
         }
         __syncthreads();
-        for (long long base = 0; base < m; base += EX_NT) {
+        for (long long base = x_begin; base < x_end; base += EX_NT) {
             long long x = base + tid;
-            if (x < m) {
-                float D = exact_dist2(qs, R + x * d, d);
-                u64 key = ((u64)__float_as_uint(D) << 32) | (u64)(unsigned)(x + col_offset);
+            if (x < x_end) {
+                u64 key;
+                if (MODE == 2) {
+                    key = parts[((long long)f * nch + x / k) * EX_PART_STRIDE + x % k];
+                } else {
+                    float D = exact_dist2(qs, R + x * d, d);
+                    key = ((u64)__float_as_uint(D) << 32) | (u64)(unsigned)(x + col_offset);
+                }
                 if (key <= thr) {
                     bool dup = false;
-                    for (int p = 0; p < k; ++p) dup |= (prior[p] == key);
+                    if (MODE != 1)  // partial lists keep entries of the prior result; mode 2 drops them
+                        for (int p = 0; p < k; ++p) dup |= (prior[p] == key);
                     if (!dup) {
                         unsigned slot = atomicAdd(&cnt, 1u);
                         cand[slot] = key;  // slot < EX_CAP: compaction below keeps EX_NT free
@@ -593,11 +649,15 @@ __global__ __launch_bounds__(EX_NT) void exact_rows_kernel(
             block_bitonic_sort(cand, np2, tid);
             if (tid < k) {
                 u64 key = (tid < (int)c) ? cand[tid] : KEY_SENTINEL;
-                bool valid = key != KEY_SENTINEL;
-                float D = __uint_as_float((unsigned)(key >> 32));
-                idx_io[q * k + tid] = valid ? (int)(unsigned)key : -1;
-                d2_io[q * k + tid] = valid ? D : __builtin_inff();
-                if (dist_out) dist_out[q * k + tid] = valid ? sqrt_rn_f32(D) : __builtin_inff();
+                if (MODE == 1) {
+                    parts[((long long)f * nch + blockIdx.x) * EX_PART_STRIDE + tid] = key;
+                } else {
+                    bool valid = key != KEY_SENTINEL;
+                    float D = __uint_as_float((unsigned)(key >> 32));
+                    idx_io[q * k + tid] = valid ? (int)(unsigned)key : -1;
+                    d2_io[q * k + tid] = valid ? D : __builtin_inff();
+                    if (dist_out) dist_out[q * k + tid] = valid ? sqrt_rn_f32(D) : __builtin_inff();
+                }
             }
         }
     }
@@ -607,6 +667,10 @@ __global__ __launch_bounds__(EX_NT) void exact_rows_kernel(
 // host-side launchers
 // --------------------------------------------------------------------------------
 static const int kD2Sizes[] = {8, 15, 16, 20, 25, 32, 40, 50, 64};
+// compiled (D2, waves per block, reference rows per LDS stage) combinations
+#define SCMIAC_FUSED_VARIANTS(X) \
+    X(8, 8, 128) X(15, 8, 128) X(16, 8, 128) X(20, 8, 128) X(25, 8, 128) X(32, 8, 128) \
+    X(40, 8, 64) X(50, 8, 64) X(64, 8, 64) X(25, 4, 64) X(25, 4, 128) X(25, 2, 64)
 
 int knn_pick_d2(int d) {
     int need = (d + 1) / 2;
@@ -618,17 +682,17 @@ int knn_pick_d2(int d) {
 template <int D2, int NW, int RT>
 static hipError_t launch_fused_t(const float* Qp, const float* Rp, const float* rnorm, u64* lists,
                                  long long n, long long n_pad, int nqb, int S, long long chunk_rows,
-                                 int kt, u64* diag, hipStream_t stream) {
+                                 const FusedTail& tail, int kt, u64* diag, hipStream_t stream) {
     using C = FusedCfg<D2, NW, RT>;
     size_t lds = C::lds_bytes();
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_knn_kernel<D2, NW, RT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    dim3 grid((unsigned)(nqb * S)), block(NW * 64);
+    dim3 grid((unsigned)(tail.block0 + (nqb - tail.qb0) * tail.St)), block(NW * 64);
     int ablate = 0;
     if (const char* v = getenv("SCMIAC_FUSED_ABLATE")) ablate = atoi(v);  // diagnostic builds only
     hipLaunchKernelGGL((fused_knn_kernel<D2, NW, RT>), grid, block, lds, stream, Qp, Rp, rnorm, lists, n,
-                       n_pad, nqb, chunk_rows, kt, ablate, diag);
+                       n_pad, nqb, chunk_rows, tail, kt, ablate, diag);
     return hipGetLastError();
 }
 
@@ -640,6 +704,39 @@ static void fused_variant(int D2, int* nw, int* rt) {
         int a = 0, b = 0;
         if (sscanf(v, "%dx%d", &a, &b) == 2 && D2 == 25) { *nw = a; *rt = b; }
     }
+}
+
+// blocks of the fused kernel the GPU runs at once (256 one-block CUs when no device answers)
+template <int D2, int NW, int RT>
+static int fused_occupancy_t() {
+    using C = FusedCfg<D2, NW, RT>;
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
+        (void)hipGetLastError();
+        return 256;
+    }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_knn_kernel<D2, NW, RT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes());
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_knn_kernel<D2, NW, RT>, NW * 64,
+                                                     C::lds_bytes()) != hipSuccess || per_cu <= 0) {
+        (void)hipGetLastError();
+        per_cu = 1;
+    }
+    return cus * per_cu;
+}
+static int fused_concurrent_blocks(const KnnGeometry& g) {
+    static int cache[16][3];  // (D2, nw, RT) -> slots; a handful of variants exist
+    static int n_cached = 0;
+    for (int i = 0; i < n_cached; ++i)
+        if (cache[i][0] == g.D2 * 100000 + g.nw * 1000 + g.RT) return cache[i][1];
+    int slots = 256;
+#define SCMIAC_OCC_CASE(V_, NW_, RT_) \
+    if (g.D2 == V_ && g.nw == NW_ && g.RT == RT_) slots = fused_occupancy_t<V_, NW_, RT_>();
+    SCMIAC_FUSED_VARIANTS(SCMIAC_OCC_CASE)
+#undef SCMIAC_OCC_CASE
+    if (n_cached < 16) { cache[n_cached][0] = g.D2 * 100000 + g.nw * 1000 + g.RT; cache[n_cached][1] = slots; ++n_cached; }
+    return slots;
 }
 
 KnnGeometry knn_geometry(long long n, long long m, int d, int splits) {
@@ -670,6 +767,43 @@ KnnGeometry knn_geometry(long long n, long long m, int d, int splits) {
     g.S = (int)((m + g.chunk_rows - 1) / g.chunk_rows);
     if (g.S < 1) g.S = 1;
     g.m_pad = (long long)g.S * g.chunk_rows;
+
+    // Tail region.  The grid runs in rounds of `slots` concurrent blocks; when every
+    // block scans the whole reference set, the query blocks of the last, partly filled
+    // round are cut into St reference chunks each so that the round is short and full.
+    FusedTail& t = g.tail;
+    t.qb0 = g.nqb; t.St = 1; t.block0 = g.nqb * g.S; t.chunk_rows = g.chunk_rows; t.m_pad = g.m_pad;
+    t.rows = 0; t.lists_row0 = (long long)g.S * g.n_pad; t.qpb = g.qpb;
+    const char* no_tail = getenv("SCMIAC_FUSED_NO_TAIL");  // tuning aid
+    int slots = fused_concurrent_blocks(g);
+    long long min_chunk = 16384;  // shortest tail chunk worth its shortlist warm-up
+    // test aids: pretend the GPU runs fewer blocks at once / allow short chunks, so that
+    // small problems exercise the tail region
+    if (const char* v = getenv("SCMIAC_FUSED_SLOTS")) { int a = atoi(v); if (a > 0) slots = a; }
+    if (const char* v = getenv("SCMIAC_FUSED_TAIL_MIN_ROWS")) { int a = atoi(v); if (a > 0) min_chunk = a; }
+    if (splits <= 0 && g.S == 1 && g.nqb > slots && g.nqb % slots != 0 && !(no_tail && no_tail[0] == '1')) {
+        const int tail_blocks = g.nqb % slots;
+        long long st_max = g.m_pad / min_chunk;
+        if (st_max > 32) st_max = 32;
+        int best = 1;
+        double best_cost = 1.0;
+        for (int st = 2; st <= st_max; ++st) {
+            long long rounds = ((long long)tail_blocks * st + slots - 1) / slots;
+            // each chunk pays for filling its shortlist from scratch (about 4096 rows' worth)
+            double cost = (double)rounds / st * (1.0 + 4096.0 * st / (double)g.m_pad);
+            if (cost < best_cost - 1e-9) { best_cost = cost; best = st; }
+        }
+        if (best > 1) {
+            t.St = best;
+            t.qb0 = g.nqb - tail_blocks;
+            t.block0 = t.qb0;  // S == 1
+            long long per_t = (g.m_pad / g.RT + best - 1) / best;
+            t.chunk_rows = per_t * g.RT;
+            t.rows = (long long)tail_blocks * g.qpb;
+        }
+    }
+    g.list_rows = (long long)g.S * g.n_pad + (long long)(t.St - 1) * t.rows;
+    g.blocks = t.block0 + (g.nqb - t.qb0) * t.St;
     return g;
 }
 
@@ -686,19 +820,8 @@ hipError_t launch_fused(const KnnGeometry& g, const float* Qp, const float* Rp, 
                         hipStream_t stream) {
 #define SCMIAC_FUSED_CASE(V_, NW_, RT_)                                                            \
     if (g.D2 == V_ && g.nw == NW_ && g.RT == RT_)                                                  \
-        return launch_fused_t<V_, NW_, RT_>(Qp, Rp, rnorm, lists, n, g.n_pad, g.nqb, g.S, g.chunk_rows, kt, diag, stream);
-    SCMIAC_FUSED_CASE(8, 8, 128)
-    SCMIAC_FUSED_CASE(15, 8, 128)
-    SCMIAC_FUSED_CASE(16, 8, 128)
-    SCMIAC_FUSED_CASE(20, 8, 128)
-    SCMIAC_FUSED_CASE(25, 8, 128)
-    SCMIAC_FUSED_CASE(32, 8, 128)
-    SCMIAC_FUSED_CASE(40, 8, 64)
-    SCMIAC_FUSED_CASE(50, 8, 64)
-    SCMIAC_FUSED_CASE(64, 8, 64)
-    SCMIAC_FUSED_CASE(25, 4, 64)
-    SCMIAC_FUSED_CASE(25, 4, 128)
-    SCMIAC_FUSED_CASE(25, 2, 64)
+        return launch_fused_t<V_, NW_, RT_>(Qp, Rp, rnorm, lists, n, g.n_pad, g.nqb, g.S, g.chunk_rows, g.tail, kt, diag, stream);
+    SCMIAC_FUSED_VARIANTS(SCMIAC_FUSED_CASE)
     return hipErrorInvalidValue;
 #undef SCMIAC_FUSED_CASE
 }
@@ -717,7 +840,7 @@ hipError_t launch_refine(const float* Q, const float* R, int d, long long n, con
     double err_abs_coef = 2.0 * G;
     double rel_keep = 1.0 - 2.0 * (double)(d + 4) * u;
     dim3 block(256), grid((unsigned)((n + 3) / 4));
-    hipLaunchKernelGGL(refine_kernel, grid, block, 0, stream, Q, R, d, n, g.n_pad, lists, g.S, k, kt,
+    hipLaunchKernelGGL(refine_kernel, grid, block, 0, stream, Q, R, d, n, g.n_pad, lists, g.S, g.tail, k, kt,
                        col_offset, merge, err_abs_coef, rel_keep, maxnorm_bits, idx, d2, dist, lb,
                        fail_rows, n_fail);
     return hipGetLastError();
@@ -725,12 +848,33 @@ hipError_t launch_refine(const float* Q, const float* R, int d, long long n, con
 
 hipError_t launch_exact_rows(const float* Q, const float* R, int d, long long n, long long m, int k,
                              long long col_offset, const int* rows, const int* n_rows, int* idx,
-                             float* d2, float* dist, hipStream_t stream) {
-    long long gmax = n < 2048 ? n : 2048;
-    if (gmax < 1) gmax = 1;
-    dim3 block(EX_NT), grid((unsigned)gmax);
-    hipLaunchKernelGGL(exact_rows_kernel, grid, block, 0, stream, Q, R, d, m, k, col_offset, rows, n_rows,
-                       idx, d2, dist);
+                             float* d2, float* dist, void* scratch, size_t scratch_bytes,
+                             hipStream_t stream) {
+    // With scratch memory the first rows of the list are searched by many blocks each.
+    int nch = (int)((m + 1023) / 1024);
+    if (nch > 256) nch = 256;
+    long long row_limit = 0;
+    if (scratch && nch >= 2) {
+        row_limit = (long long)(scratch_bytes / (sizeof(u64) * EX_PART_STRIDE * (size_t)nch));
+        if (row_limit > n) row_limit = n;
+        if (row_limit > 4096) row_limit = 4096;
+    }
+    u64* parts = static_cast<u64*>(scratch);
+    if (row_limit > 0) {
+        long long chunk_len = (m + nch - 1) / nch;
+        unsigned ry = (unsigned)(row_limit < 16 ? row_limit : 16);
+        hipLaunchKernelGGL(exact_rows_kernel<1>, dim3((unsigned)nch, ry), dim3(EX_NT), 0, stream, Q, R, d, m, k,
+                           col_offset, rows, n_rows, idx, d2, dist, parts, nch, chunk_len, 0, (int)row_limit);
+        unsigned gb = (unsigned)(row_limit < 256 ? row_limit : 256);
+        hipLaunchKernelGGL(exact_rows_kernel<2>, dim3(gb), dim3(EX_NT), 0, stream, Q, R, d, m, k, col_offset,
+                           rows, n_rows, idx, d2, dist, parts, nch, chunk_len, 0, (int)row_limit);
+    }
+    long long rest = n - row_limit;  // listed rows beyond the scratch capacity
+    if (rest > 0) {
+        long long gmax = rest < 2048 ? rest : 2048;
+        hipLaunchKernelGGL(exact_rows_kernel<0>, dim3((unsigned)gmax), dim3(EX_NT), 0, stream, Q, R, d, m, k,
+                           col_offset, rows, n_rows, idx, d2, dist, parts, nch, 0ll, (int)row_limit, 0);
+    }
     return hipGetLastError();
 }
 

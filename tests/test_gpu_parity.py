@@ -118,6 +118,35 @@ def test_knn_exact_rows_alone():
     np.testing.assert_array_equal(st.dist2.cpu().numpy(), d2_o)
 
 
+@pytest.mark.parametrize("scratch_rows", [0, 1, 64])
+def test_knn_exact_rows_scratch_modes(scratch_rows):
+    """Without scratch every listed row is scanned by one block; with scratch the first
+    rows are scanned by many blocks each (scratch_rows=1 covers 51 of the 64 rows here,
+    the rest take the one-block path).  Same result either way."""
+    Q = _mixture(43, 64, 50)
+    R = _mixture(44, 5300, 50)
+    st = _hip.knn_search(_dev(Q), _dev(R[:300]), 30, exact_fallback=False)
+    rows = torch.arange(64, dtype=torch.int32, device="cuda")
+    n_rows = torch.tensor([64], dtype=torch.int32, device="cuda")
+    _hip.knn_exact_rows(_dev(Q), _dev(R[300:]), 30, rows, n_rows, st, col_offset=300, scratch_rows=scratch_rows)
+    torch.cuda.synchronize()
+    idx_o, d2_o = oracle.knn_dist2(Q, R, 30)
+    np.testing.assert_array_equal(st.idx.cpu().numpy(), idx_o)
+    np.testing.assert_array_equal(st.dist2.cpu().numpy(), d2_o)
+
+
+def test_knn_tail_region(monkeypatch):
+    """The query blocks of the grid's last round search the references in several
+    chunks each.  Forced at a small size by pretending the GPU runs 8 blocks at once."""
+    monkeypatch.setenv("SCMIAC_FUSED_SLOTS", "8")
+    monkeypatch.setenv("SCMIAC_FUSED_TAIL_MIN_ROWS", "1024")
+    Q = _mixture(61, 3000, 50)              # 12 query blocks: 8 + a tail of 4
+    R = _mixture(62, 20000, 50, offset=True)
+    R[5000:5100] = R[3]                      # ties across tail chunks -> direct evaluation too
+    _check_knn(Q, R, 30)
+    _check_knn(Q[:2100], R, 31)             # 9 blocks: tail of 1
+
+
 def test_knn_distances_within_tolerance_of_float64():
     Q = _mixture(51, 800, 50)
     R = _mixture(52, 4000, 50, offset=True)

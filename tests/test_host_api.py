@@ -89,3 +89,24 @@ def test_label_codes_follow_string_equality():
     c1, c2 = label_codes(a, b)
     eq = a.astype(str)[:, None] == b.astype(str)[None, :]
     np.testing.assert_array_equal(c1[:, None] == c2[None, :], eq)
+
+
+def test_tail_region_enlarges_workspace(monkeypatch):
+    """The last, partly filled round of query blocks searches the references in
+    several chunks: those chunks need shortlists of their own."""
+    from scmiac_amd import _hip
+
+    lib = _hip.load_library()
+
+    def size():
+        b = ctypes.c_size_t()
+        assert lib.scmiac_knn_workspace_size(3000, 20000, 50, 30, 0, ctypes.byref(b)) == 0
+        return b.value
+
+    monkeypatch.setenv("SCMIAC_FUSED_NO_TAIL", "1")
+    plain = size()
+    monkeypatch.delenv("SCMIAC_FUSED_NO_TAIL")
+    assert size() == plain            # 12 query blocks never fill 256 compute units: no tail
+    monkeypatch.setenv("SCMIAC_FUSED_SLOTS", "8")
+    monkeypatch.setenv("SCMIAC_FUSED_TAIL_MIN_ROWS", "1024")
+    assert size() > plain             # 8 + a tail of 4 blocks
