@@ -161,6 +161,16 @@ SCMIAC_API int scmiac_knn_diag_region(int64_t n, int64_t m, int d, int k, int sp
                                       size_t *bytes, int *waves);
 
 /*
+ * How scmiac_knn_search would lay its fused kernel's grid out for this problem (no
+ * counterpart in the reference; no GPU work).  plan[8] (host memory):
+ *   {query blocks, queries per block, S, rows per chunk, main query blocks,
+ *    St, rows per tail chunk, grid blocks}
+ * Query blocks below "main query blocks" are searched in S reference chunks each; the
+ * rest -- what would be a partly filled last round of the grid -- in St chunks each.
+ */
+SCMIAC_API int scmiac_knn_grid_plan(int64_t n, int64_t m, int d, int k, int splits, int64_t *plan);
+
+/*
  * Optional in-library timing of the fused distance + top-k kernel (no counterpart
  * in the reference).  While enabled, every scmiac_knn_search brackets that kernel's
  * launch with a pair of HIP events on `stream` (up to 256 searches; enabling again

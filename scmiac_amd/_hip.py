@@ -38,6 +38,7 @@ _SIGNATURES = {
                               _vp, _vp, _vp, _vp, _vp, _sz, _vp], _c.c_int),
     "scmiac_knn_diag_region": ([_i64, _i64, _i32, _i32, _i32, _c.POINTER(_sz), _c.POINTER(_sz),
                                 _c.POINTER(_c.c_int)], _c.c_int),
+    "scmiac_knn_grid_plan": ([_i64, _i64, _i32, _i32, _i32, _c.POINTER(_i64)], _c.c_int),
     "scmiac_knn_set_timing": ([_i32], _c.c_int),
     "scmiac_knn_fused_ms": ([_c.POINTER(_c.c_float), _c.POINTER(_c.c_int)], _c.c_int),
 }
@@ -252,6 +253,15 @@ def knn_diag(n, m, d, k, splits=0, device=None):
     device = device or torch.device("cuda", torch.cuda.current_device())
     ws = _ws_cache[device]
     return ws[off.value:off.value + nbytes.value].view(torch.int64).view(waves.value, 8).cpu().numpy()
+
+
+def knn_grid_plan(n, m, d, k, splits=0):
+    """Grid layout of the fused kernel for this problem (needs no GPU)."""
+    plan = (_i64 * 8)()
+    _check(load_library().scmiac_knn_grid_plan(n, m, d, k, splits, plan))
+    names = ("query_blocks", "queries_per_block", "S", "chunk_rows", "main_query_blocks", "St",
+             "tail_chunk_rows", "grid_blocks")
+    return dict(zip(names, (int(v) for v in plan)))
 
 
 def set_timing(enabled: bool):

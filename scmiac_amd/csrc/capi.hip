@@ -88,7 +88,7 @@ int scmiac_knn_workspace_size(int64_t n, int64_t m, int d, int k, int splits, si
     if (!bytes) return fail(SCMIAC_ERR_ARG, "bytes is NULL");
     int rc = check_knn_args(n, m, d, k);
     if (rc) return rc;
-    KnnGeometry g = knn_geometry(n, m, d, splits);
+    KnnGeometry g = knn_geometry(n, m, d, k, splits);
     if (g.D2 < 0) return fail(SCMIAC_ERR_ARG, "unsupported feature dimension %d", d);
     *bytes = knn_carve(nullptr, n, g).total;
     return SCMIAC_OK;
@@ -99,12 +99,23 @@ int scmiac_knn_diag_region(int64_t n, int64_t m, int d, int k, int splits, size_
     if (!offset || !bytes || !waves) return fail(SCMIAC_ERR_ARG, "NULL output pointer");
     int rc = check_knn_args(n, m, d, k);
     if (rc) return rc;
-    KnnGeometry g = knn_geometry(n, m, d, splits);
+    KnnGeometry g = knn_geometry(n, m, d, k, splits);
     if (g.D2 < 0) return fail(SCMIAC_ERR_ARG, "unsupported feature dimension %d", d);
     KnnWs w = knn_carve(nullptr, n, g);
     *offset = w.diag_offset;
     *bytes = w.diag_bytes;
     *waves = g.blocks * g.nw;
+    return SCMIAC_OK;
+}
+
+int scmiac_knn_grid_plan(int64_t n, int64_t m, int d, int k, int splits, int64_t* plan) {
+    if (!plan) return fail(SCMIAC_ERR_ARG, "plan is NULL");
+    int rc = check_knn_args(n, m, d, k);
+    if (rc) return rc;
+    KnnGeometry g = knn_geometry(n, m, d, k, splits);
+    if (g.D2 < 0) return fail(SCMIAC_ERR_ARG, "unsupported feature dimension %d", d);
+    plan[0] = g.nqb; plan[1] = g.qpb; plan[2] = g.S; plan[3] = g.chunk_rows;
+    plan[4] = g.tail.qb0; plan[5] = g.tail.St; plan[6] = g.tail.chunk_rows; plan[7] = g.blocks;
     return SCMIAC_OK;
 }
 
@@ -120,7 +131,7 @@ int scmiac_knn_search(const float* q, int64_t n, const float* r, int64_t m, int 
         return fail(SCMIAC_ERR_ARG, "NULL device pointer");
     if (m > 0 && !r) return fail(SCMIAC_ERR_ARG, "NULL reference pointer");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    KnnGeometry g = knn_geometry(n, m, d, splits);
+    KnnGeometry g = knn_geometry(n, m, d, k, splits);
     if (g.D2 < 0) return fail(SCMIAC_ERR_ARG, "unsupported feature dimension %d", d);
     KnnWs w = knn_carve(workspace, n, g);
     if (w.total > workspace_bytes)

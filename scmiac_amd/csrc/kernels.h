@@ -46,7 +46,7 @@ int knn_pick_d2(int d);
 // rank of the shortlist entry whose key serves as the running threshold: the k wanted
 // neighbours plus a margin that the rounding-error certificate can absorb
 inline int knn_threshold_rank(int k) { return (k + 6 < 64) ? k + 6 : 64; }
-KnnGeometry knn_geometry(long long n, long long m, int d, int splits);
+KnnGeometry knn_geometry(long long n, long long m, int d, int k, int splits);
 
 hipError_t launch_pack(const float* X, long long n, int d, const KnnGeometry& g, float scale, float* Xp,
                        int ld, float* norms, long long n_pad, unsigned* maxnorm_bits, hipStream_t stream);

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <math.h>
 #include <stdlib.h>
 
 #include <type_traits>
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(NW_ * 64, 2) void fused_knn_kernel(
     long long r_begin, rows_here;
     long long list_row;  // row of the [.][64] shortlist array this wave's first query uses
     if ((int)blockIdx.x < tail.block0) {
-        split = blockIdx.x / nqb; qb = blockIdx.x % nqb;
+        split = blockIdx.x / tail.qb0; qb = blockIdx.x % tail.qb0;  // main region: qb0 query blocks
         r_begin = (long long)split * chunk_rows;
         rows_here = chunk_rows;
         list_row = (long long)split * n_pad + (long long)qb * C::QPB + wave * 32;
@@ -482,7 +483,7 @@ __global__ __launch_bounds__(256) void refine_kernel(
         lb = lower_bound[q];
     }
     const long long tail_q0 = (long long)tail.qb0 * tail.qpb;
-    const bool in_tail = tail.St > 1 && q >= tail_q0;
+    const bool in_tail = q >= tail_q0;
     const int S_q = in_tail ? tail.St : S;
     for (int s = 0; s < S_q; ++s) {
         long long lrow = (long long)s * n_pad + q;
@@ -739,7 +740,7 @@ static int fused_concurrent_blocks(const KnnGeometry& g) {
     return slots;
 }
 
-KnnGeometry knn_geometry(long long n, long long m, int d, int splits) {
+KnnGeometry knn_geometry(long long n, long long m, int d, int k, int splits) {
     KnnGeometry g{};
     g.D2 = knn_pick_d2(d);
     if (g.D2 < 0) return g;
@@ -750,57 +751,77 @@ KnnGeometry knn_geometry(long long n, long long m, int d, int splits) {
     g.qpb = g.nw * 32;
     g.n_pad = ((n + g.qpb - 1) / g.qpb) * g.qpb;
     g.nqb = (int)(g.n_pad / g.qpb);
-    int S = splits;
-    if (S <= 0) {
-        // enough (query block, reference chunk) units to fill 256 CUs a few times over,
-        // but chunks long enough that the per-chunk shortlist warm-up stays small
-        long long want = (1024 + g.nqb - 1) / g.nqb;
-        long long cap = m / 16384;
-        if (cap < 1) cap = 1;
-        S = (int)(want < cap ? want : cap);
-        if (S > 64) S = 64;
-        if (S < 1) S = 1;
+    const long long rows_rt = (m + g.RT - 1) / g.RT;  // reference rows in units of one LDS stage
+    int slots = fused_concurrent_blocks(g);
+    long long min_chunk = 8192;  // shortest reference chunk considered
+    // test aids: pretend the GPU runs fewer blocks at once / allow short chunks, so that
+    // small problems exercise every region of the grid
+    if (const char* v = getenv("SCMIAC_FUSED_SLOTS")) { int a = atoi(v); if (a > 0) slots = a; }
+    if (const char* v = getenv("SCMIAC_FUSED_TAIL_MIN_ROWS")) { int a = atoi(v); if (a > 0) min_chunk = a; }
+    const char* no_tail = getenv("SCMIAC_FUSED_NO_TAIL");  // tuning aid
+
+    // Grid plan.  Query blocks [0, qb0) ("main") are searched in S reference chunks each,
+    // qb0 * S being a whole number of rounds of `slots` concurrent blocks; the remaining
+    // query blocks ("tail") would leave the last round partly empty and are searched in St
+    // chunks each instead.  More chunks = more, shorter blocks (fuller rounds) but every
+    // chunk refills its shortlist from scratch and adds a list per query to the refine
+    // pass.  (S, St) minimise a cycle model of the fused kernel fitted on MI355X.
+    int S = 1, St = 1, qb0 = g.nqb;
+    if (splits > 0) {
+        S = splits;
+        if (S > rows_rt) S = (int)(rows_rt > 0 ? rows_rt : 1);
+    } else {
+        const double kt = (double)knn_threshold_rank(k);
+        auto block_cycles = [&](double chunk) {
+            if (chunk < 64.0) chunk = 64.0;
+            const double sub = chunk / 32.0;                   // 32-row subtiles
+            const double dense = 1024.0 * kt;                  // rows over which every subtile has candidates
+            const double entries = chunk <= dense ? sub : dense / 32.0 * (1.0 + log(chunk / dense));
+            const double merges = 64.0 + kt * log(chunk / 64.0);
+            return sub * (g.D2 * 152.0) + entries * 2300.0 + merges * 4400.0;
+        };
+        long long s_max = (long long)rows_rt * g.RT / min_chunk;
+        if (s_max > 64) s_max = 64;
+        if (s_max < 1) s_max = 1;
+        double best = 1e300;
+        for (int s = 1; s <= s_max; ++s) {
+            int gcd = s, b = slots;
+            while (b) { int tmp = gcd % b; gcd = b; b = tmp; }
+            const int step = slots / gcd;  // main query blocks come in multiples of this
+            int q0 = (g.nqb / step) * step;
+            if (no_tail && no_tail[0] == '1') q0 = g.nqb;
+            const double chunk_s = (double)m / s;
+            const double main_cost = (double)((long long)q0 * s / slots) * block_cycles(chunk_s);
+            const int tail_blocks = g.nqb - q0;
+            const double refine_main = 43.0 * (double)q0 * g.qpb * s;
+            if (tail_blocks == 0) {
+                const double c = main_cost + refine_main;
+                if (c < best) { best = c; S = s; St = 1; qb0 = q0; }
+                continue;
+            }
+            if (s > 1 && q0 == 0) continue;  // an all-tail plan does not depend on s: counted once
+            for (int st = 1; st <= s_max; ++st) {
+                const long long rounds = ((long long)tail_blocks * st + slots - 1) / slots;
+                const double c = main_cost + refine_main + (double)rounds * block_cycles((double)m / st) +
+                                 43.0 * (double)tail_blocks * g.qpb * st;
+                if (c < best) { best = c; S = s; St = st; qb0 = q0; }
+            }
+        }
     }
-    long long per = (m + S - 1) / S;
-    g.chunk_rows = ((per + g.RT - 1) / g.RT) * g.RT;
+    long long per = (rows_rt + S - 1) / S;
+    g.chunk_rows = per * g.RT;
     if (g.chunk_rows == 0) g.chunk_rows = g.RT;
-    g.S = (int)((m + g.chunk_rows - 1) / g.chunk_rows);
+    g.S = (int)((rows_rt * g.RT + g.chunk_rows - 1) / g.chunk_rows);
     if (g.S < 1) g.S = 1;
     g.m_pad = (long long)g.S * g.chunk_rows;
 
-    // Tail region.  The grid runs in rounds of `slots` concurrent blocks; when every
-    // block scans the whole reference set, the query blocks of the last, partly filled
-    // round are cut into St reference chunks each so that the round is short and full.
     FusedTail& t = g.tail;
-    t.qb0 = g.nqb; t.St = 1; t.block0 = g.nqb * g.S; t.chunk_rows = g.chunk_rows; t.m_pad = g.m_pad;
-    t.rows = 0; t.lists_row0 = (long long)g.S * g.n_pad; t.qpb = g.qpb;
-    const char* no_tail = getenv("SCMIAC_FUSED_NO_TAIL");  // tuning aid
-    int slots = fused_concurrent_blocks(g);
-    long long min_chunk = 16384;  // shortest tail chunk worth its shortlist warm-up
-    // test aids: pretend the GPU runs fewer blocks at once / allow short chunks, so that
-    // small problems exercise the tail region
-    if (const char* v = getenv("SCMIAC_FUSED_SLOTS")) { int a = atoi(v); if (a > 0) slots = a; }
-    if (const char* v = getenv("SCMIAC_FUSED_TAIL_MIN_ROWS")) { int a = atoi(v); if (a > 0) min_chunk = a; }
-    if (splits <= 0 && g.S == 1 && g.nqb > slots && g.nqb % slots != 0 && !(no_tail && no_tail[0] == '1')) {
-        const int tail_blocks = g.nqb % slots;
-        long long st_max = g.m_pad / min_chunk;
-        if (st_max > 32) st_max = 32;
-        int best = 1;
-        double best_cost = 1.0;
-        for (int st = 2; st <= st_max; ++st) {
-            long long rounds = ((long long)tail_blocks * st + slots - 1) / slots;
-            // each chunk pays for filling its shortlist from scratch (about 4096 rows' worth)
-            double cost = (double)rounds / st * (1.0 + 4096.0 * st / (double)g.m_pad);
-            if (cost < best_cost - 1e-9) { best_cost = cost; best = st; }
-        }
-        if (best > 1) {
-            t.St = best;
-            t.qb0 = g.nqb - tail_blocks;
-            t.block0 = t.qb0;  // S == 1
-            long long per_t = (g.m_pad / g.RT + best - 1) / best;
-            t.chunk_rows = per_t * g.RT;
-            t.rows = (long long)tail_blocks * g.qpb;
-        }
+    t.qb0 = qb0; t.St = St; t.block0 = qb0 * g.S; t.qpb = g.qpb; t.m_pad = g.m_pad;
+    t.rows = (long long)(g.nqb - qb0) * g.qpb;
+    t.lists_row0 = (long long)g.S * g.n_pad;
+    {
+        long long per_t = (g.m_pad / g.RT + St - 1) / St;
+        t.chunk_rows = per_t * g.RT;
     }
     g.list_rows = (long long)g.S * g.n_pad + (long long)(t.St - 1) * t.rows;
     g.blocks = t.block0 + (g.nqb - t.qb0) * t.St;

@@ -91,22 +91,28 @@ def test_label_codes_follow_string_equality():
     np.testing.assert_array_equal(c1[:, None] == c2[None, :], eq)
 
 
-def test_tail_region_enlarges_workspace(monkeypatch):
-    """The last, partly filled round of query blocks searches the references in
-    several chunks: those chunks need shortlists of their own."""
+def test_grid_plan(monkeypatch):
+    """Main query blocks fill whole rounds of concurrent blocks; the rest (the tail)
+    are cut into more reference chunks so that the last round is short and full."""
     from scmiac_amd import _hip
 
-    lib = _hip.load_library()
-
-    def size():
-        b = ctypes.c_size_t()
-        assert lib.scmiac_knn_workspace_size(3000, 20000, 50, 30, 0, ctypes.byref(b)) == 0
-        return b.value
-
-    monkeypatch.setenv("SCMIAC_FUSED_NO_TAIL", "1")
-    plain = size()
-    monkeypatch.delenv("SCMIAC_FUSED_NO_TAIL")
-    assert size() == plain            # 12 query blocks never fill 256 compute units: no tail
+    # 256 compute units, one block each (what the library assumes when no GPU answers)
+    p = _hip.knn_grid_plan(1_000_000, 1_000_000, 50, 30)
+    assert p["query_blocks"] == 3907 and p["queries_per_block"] == 256
+    assert p["S"] == 1 and p["main_query_blocks"] == 3840 and p["St"] > 1
+    assert p["grid_blocks"] == 3840 + 67 * p["St"]
+    assert p["tail_chunk_rows"] * p["St"] >= 1_000_000
+    # a whole number of rounds: nothing to cut
+    p = _hip.knn_grid_plan(262144, 1_000_000, 50, 30)
+    assert p["S"] == 1 and p["main_query_blocks"] == 1024 and p["grid_blocks"] == 1024
+    # few query blocks: all of them are cut, so that the grid still fills the GPU
+    p = _hip.knn_grid_plan(10_000, 1_000_000, 50, 30)
+    assert p["main_query_blocks"] == 0 and p["grid_blocks"] == 40 * p["St"] >= 200
+    # an explicit number of chunks is taken as given
+    p = _hip.knn_grid_plan(3000, 20000, 50, 30, splits=7)
+    assert p["S"] == 7 and p["main_query_blocks"] == 12 and p["grid_blocks"] == 84
+    # test aid: a pretend 8-slot GPU makes small problems grow a tail
     monkeypatch.setenv("SCMIAC_FUSED_SLOTS", "8")
     monkeypatch.setenv("SCMIAC_FUSED_TAIL_MIN_ROWS", "1024")
-    assert size() > plain             # 8 + a tail of 4 blocks
+    p = _hip.knn_grid_plan(3000, 20000, 50, 30)
+    assert p["main_query_blocks"] in (8, 12) and p["grid_blocks"] >= 12
