@@ -20,6 +20,7 @@ Rank 0 prints one JSON line.  Next to the headline it carries
                   timed on this box's host cores on a bounded sample of query rows;
                   the same rows double as the parity check of the GPU result
   full_search  -- all four tables + MNN + SNN score + label filter (one anchor search)
+  pcie_inclusive -- one table with inputs starting and the result ending in host memory
 """
 from __future__ import annotations
 
@@ -36,7 +37,7 @@ import torch
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-from scmiac_amd import _hip, anchor_search  # noqa: E402
+from scmiac_amd import _hip, anchor_search, sharded  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X dense fp32 matrix peak (256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz)
 
@@ -67,13 +68,13 @@ def make_latents(name, n=None, m=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--n", type=int, default=None, help="override the number of query cells")
     ap.add_argument("--m", type=int, default=None, help="override the number of reference cells")
     ap.add_argument("--k", type=int, default=30)
-    ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU baseline sample (0 = auto, about 15 s)")
+    ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU baseline sample (0 = auto: about 15 s of CPU work)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline / parity sample")
     ap.add_argument("--no-full", action="store_true", help="skip the full four-table anchor search timing")
     args = ap.parse_args()
@@ -93,19 +94,14 @@ def main():
     U, V, l1, l2, d = make_latents(args.workload, args.n, args.m)
     n, m, k = U.shape[0], V.shape[0], args.k
     # query-row shard of this rank (contiguous blocks; references replicated)
-    per = (n + world - 1) // world
-    lo, hi = min(rank * per, n), min((rank + 1) * per, n)
+    lo, hi = sharded.shard_bounds(n, world, rank)
     q_dev = torch.from_numpy(U[lo:hi]).to(dev)
     r_dev = torch.from_numpy(V).to(dev)
-    gathered = torch.empty((world * per, k), dtype=torch.int32, device=dev) if distributed else None
 
     def step():
-        st = _hip.knn_search(q_dev, r_dev, k)
+        st = sharded.knn_replicated(q_dev, r_dev, k)
         if distributed:
-            part = st.idx
-            if part.shape[0] < per:  # last shard: pad so every rank contributes equally
-                part = torch.cat([part, part.new_full((per - part.shape[0], k), -1)])
-            dist.all_gather_into_tensor(gathered, part)
+            st.gathered = sharded.gather_rows(st.idx, n)  # every rank ends up with the whole table
         return st
 
     def fence():
@@ -162,6 +158,12 @@ def main():
         "roofline": roofline,
     }
 
+    if distributed:  # the gathered table is the shards' tables in rank order
+        assert torch.equal(st.gathered[lo:hi], st.idx)
+
+    if rank == 0 and not distributed and not args.no_full:
+        out["pcie_inclusive"] = pcie_inclusive(U, V, k, dev)
+
     if rank == 0 and not args.no_cpu:
         out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(U[lo:hi], V, k, st, args.cpu_rows)
 
@@ -173,6 +175,23 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+
+
+def pcie_inclusive(U, V, k, dev):
+    """One table with the inputs starting in (pinned) host memory and the index table
+    ending there: H2D of Q and R + search + D2H.  Reported next to the headline, never as it."""
+    u, v = torch.from_numpy(U).pin_memory(), torch.from_numpy(V).pin_memory()
+    out = torch.empty((U.shape[0], k), dtype=torch.int32).pin_memory()
+    best = float("inf")
+    for _ in range(2):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        st = _hip.knn_search(u.to(dev, non_blocking=True), v.to(dev, non_blocking=True), k)
+        out.copy_(st.idx, non_blocking=True)
+        torch.cuda.synchronize(dev)
+        best = min(best, time.perf_counter() - t0)
+    return {"ms_per_table": round(best * 1e3, 3), "cells_per_s": round(U.shape[0] / best, 1),
+            "h2d_bytes": int(u.numel() + v.numel()) * 4, "d2h_bytes": int(out.numel()) * 4}
 
 
 def cpu_baseline_and_parity(Q, R, k, st, rows_arg):
@@ -187,7 +206,8 @@ def cpu_baseline_and_parity(Q, R, k, st, rows_arg):
     if rows_arg > 0:
         nrows = min(rows_arg, n)
     else:
-        probe = rng.choice(n, size=min(n, 4 * cores), replace=False)
+        probe = rng.choice(n, size=min(n, 16 * cores), replace=False)
+        oracle.knn_dist2(Q[probe[:cores]], R, k)  # thread pool and caches warm
         t0 = time.perf_counter()
         oracle.knn_dist2(Q[probe], R, k)
         rate = len(probe) / max(time.perf_counter() - t0, 1e-6)
