@@ -31,6 +31,7 @@ struct KnnGeometry {
     int ls;                // row stride of the packed reference image (features, zero pad)
     int RT;                // reference rows per LDS stage
     int nw;                // waves per block of the fused kernel
+    int pcap;              // pending candidates per query (LDS buffer length)
     int qpb;               // queries per block
     int nqb;               // query blocks
     int S;                 // reference chunks searched independently

@@ -127,7 +127,7 @@ static constexpr unsigned TAU_MAX_BITS = 0x7f000000u;  // 1.7e38: above every re
 __device__ __forceinline__ float score_key(float score, int r) {
     return __uint_as_float((__float_as_uint(score) & KEY_MASK) | (unsigned)r);
 }
-template <int D2, int NW_, int RT_>
+template <int D2, int NW_, int RT_, int PCAP_>
 struct FusedCfg {
     static constexpr int D2P = (D2 + 3) & ~3;
     static constexpr int ROWF = 2 * D2P;  // feature floats per packed row
@@ -136,7 +136,7 @@ struct FusedCfg {
     static constexpr int LS = ROWF + (((ROWF / 4) % 2 == 0) ? 4 : 8);
     static constexpr int RT = RT_;                     // reference rows per LDS stage
     static constexpr int NW = NW_;                     // waves per block
-    static constexpr int PCAP = 32;                    // pending candidates per query
+    static constexpr int PCAP = PCAP_;                 // pending candidates per query
     static constexpr int QPB = NW * 32;                // queries per block
     static constexpr size_t lds_bytes() {
         return sizeof(float) * (2 * RT * LS + 2 * RT) + sizeof(uint2) * (NW * 32 * PCAP) +
@@ -195,15 +195,15 @@ __device__ __forceinline__ float flush_query(unsigned c, const uint2* pend_q, u6
     return ord2f(top);
 }
 
-template <int D2, int NW_, int RT_>
-__global__ __launch_bounds__(NW_ * 64, 2) void fused_knn_kernel(
+template <int D2, int NW_, int RT_, int PCAP_>
+__global__ __launch_bounds__(NW_ * 64, (NW_ >= 8 ? NW_ / 4 : 2)) void fused_knn_kernel(
     const float* __restrict__ Qp,     // [n_pad][ROWF], already scaled by -2
     const float* __restrict__ Rp,     // [m_pad][LS], zero pad columns
     const float* __restrict__ rnorm,  // [m_pad], 1.7e38 on padding rows
     u64* __restrict__ lists,          // [S][n_pad][64], then the tail region's extra lists
     long long n, long long n_pad, int nqb, long long chunk_rows, FusedTail tail, int kt, int ablate,
     u64* __restrict__ diag /* per wave 8 counters, or NULL (diagnostic runs only) */) {
-    using C = FusedCfg<D2, NW_, RT_>;
+    using C = FusedCfg<D2, NW_, RT_, PCAP_>;
     constexpr int D2P = C::D2P, ROWF = C::ROWF, LS = C::LS, RT = C::RT, NW = C::NW;
     constexpr int PCAP = C::PCAP, NSUB = RT / 32;
     constexpr int STAGE_BYTES = RT * LS * 4;
@@ -668,10 +668,11 @@ __global__ __launch_bounds__(EX_NT) void exact_rows_kernel(
 // host-side launchers
 // --------------------------------------------------------------------------------
 static const int kD2Sizes[] = {8, 15, 16, 20, 25, 32, 40, 50, 64};
-// compiled (D2, waves per block, reference rows per LDS stage) combinations
+// compiled (D2, waves per block, reference rows per LDS stage, pending candidates per query)
 #define SCMIAC_FUSED_VARIANTS(X) \
-    X(8, 8, 128) X(15, 8, 128) X(16, 8, 128) X(20, 8, 128) X(25, 8, 128) X(32, 8, 128) \
-    X(40, 8, 64) X(50, 8, 64) X(64, 8, 64) X(25, 4, 64) X(25, 4, 128) X(25, 2, 64)
+    X(8, 12, 128, 32) X(15, 12, 128, 32) X(16, 12, 128, 32) X(20, 12, 128, 32) X(25, 12, 128, 32) \
+    X(32, 8, 128, 32) X(40, 8, 64, 32) X(50, 8, 64, 32) X(64, 8, 64, 32) \
+    X(25, 8, 128, 32) X(25, 16, 128, 16) X(32, 12, 64, 32)
 
 int knn_pick_d2(int d) {
     int need = (d + 1) / 2;
@@ -680,46 +681,48 @@ int knn_pick_d2(int d) {
     return -1;
 }
 
-template <int D2, int NW, int RT>
+template <int D2, int NW, int RT, int PC>
 static hipError_t launch_fused_t(const float* Qp, const float* Rp, const float* rnorm, u64* lists,
                                  long long n, long long n_pad, int nqb, int S, long long chunk_rows,
                                  const FusedTail& tail, int kt, u64* diag, hipStream_t stream) {
-    using C = FusedCfg<D2, NW, RT>;
+    using C = FusedCfg<D2, NW, RT, PC>;
     size_t lds = C::lds_bytes();
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_knn_kernel<D2, NW, RT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_knn_kernel<D2, NW, RT, PC>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     dim3 grid((unsigned)(tail.block0 + (nqb - tail.qb0) * tail.St)), block(NW * 64);
     int ablate = 0;
     if (const char* v = getenv("SCMIAC_FUSED_ABLATE")) ablate = atoi(v);  // diagnostic builds only
-    hipLaunchKernelGGL((fused_knn_kernel<D2, NW, RT>), grid, block, lds, stream, Qp, Rp, rnorm, lists, n,
+    hipLaunchKernelGGL((fused_knn_kernel<D2, NW, RT, PC>), grid, block, lds, stream, Qp, Rp, rnorm, lists, n,
                        n_pad, nqb, chunk_rows, tail, kt, ablate, diag);
     return hipGetLastError();
 }
 
 // (waves per block, reference rows per LDS stage) of the fused kernel
-static void fused_variant(int D2, int* nw, int* rt) {
-    *nw = 8;
+static void fused_variant(int D2, int* nw, int* rt, int* pcap) {
+    // 12 waves (3 per SIMD) where the candidate buffers and two stages fit the 160 KiB of LDS
+    *nw = (D2 <= 25) ? 12 : 8;
     *rt = (D2 <= 32) ? 128 : 64;
-    if (const char* v = getenv("SCMIAC_FUSED_VARIANT")) {  // tuning aid: "NWxRT", e.g. 4x64
-        int a = 0, b = 0;
-        if (sscanf(v, "%dx%d", &a, &b) == 2 && D2 == 25) { *nw = a; *rt = b; }
+    *pcap = 32;
+    if (const char* v = getenv("SCMIAC_FUSED_VARIANT")) {  // tuning aid: "NWxRTxPCAP", e.g. 12x128x16
+        int a = 0, b = 0, c = 32;
+        if (sscanf(v, "%dx%dx%d", &a, &b, &c) >= 2 && (D2 == 25 || D2 == 32)) { *nw = a; *rt = b; *pcap = c; }
     }
 }
 
 // blocks of the fused kernel the GPU runs at once (256 one-block CUs when no device answers)
-template <int D2, int NW, int RT>
+template <int D2, int NW, int RT, int PC>
 static int fused_occupancy_t() {
-    using C = FusedCfg<D2, NW, RT>;
+    using C = FusedCfg<D2, NW, RT, PC>;
     int dev = 0, cus = 0, per_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
         (void)hipGetLastError();
         return 256;
     }
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_knn_kernel<D2, NW, RT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_knn_kernel<D2, NW, RT, PC>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes());
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_knn_kernel<D2, NW, RT>, NW * 64,
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_knn_kernel<D2, NW, RT, PC>, NW * 64,
                                                      C::lds_bytes()) != hipSuccess || per_cu <= 0) {
         (void)hipGetLastError();
         per_cu = 1;
@@ -727,16 +730,17 @@ static int fused_occupancy_t() {
     return cus * per_cu;
 }
 static int fused_concurrent_blocks(const KnnGeometry& g) {
-    static int cache[16][3];  // (D2, nw, RT) -> slots; a handful of variants exist
+    static int cache[32][2];  // variant -> slots; a handful of variants exist
     static int n_cached = 0;
+    const int tag = ((g.D2 * 100 + g.nw) * 1000 + g.RT) * 100 + g.pcap;
     for (int i = 0; i < n_cached; ++i)
-        if (cache[i][0] == g.D2 * 100000 + g.nw * 1000 + g.RT) return cache[i][1];
+        if (cache[i][0] == tag) return cache[i][1];
     int slots = 256;
-#define SCMIAC_OCC_CASE(V_, NW_, RT_) \
-    if (g.D2 == V_ && g.nw == NW_ && g.RT == RT_) slots = fused_occupancy_t<V_, NW_, RT_>();
+#define SCMIAC_OCC_CASE(V_, NW_, RT_, PC_) \
+    if (g.D2 == V_ && g.nw == NW_ && g.RT == RT_ && g.pcap == PC_) slots = fused_occupancy_t<V_, NW_, RT_, PC_>();
     SCMIAC_FUSED_VARIANTS(SCMIAC_OCC_CASE)
 #undef SCMIAC_OCC_CASE
-    if (n_cached < 16) { cache[n_cached][0] = g.D2 * 100000 + g.nw * 1000 + g.RT; cache[n_cached][1] = slots; ++n_cached; }
+    if (n_cached < 32) { cache[n_cached][0] = tag; cache[n_cached][1] = slots; ++n_cached; }
     return slots;
 }
 
@@ -747,7 +751,7 @@ KnnGeometry knn_geometry(long long n, long long m, int d, int k, int splits) {
     g.D2P = (g.D2 + 3) & ~3;
     g.rowf = 2 * g.D2P;
     g.ls = g.rowf + (((g.rowf / 4) % 2 == 0) ? 4 : 8);
-    fused_variant(g.D2, &g.nw, &g.RT);
+    fused_variant(g.D2, &g.nw, &g.RT, &g.pcap);
     g.qpb = g.nw * 32;
     g.n_pad = ((n + g.qpb - 1) / g.qpb) * g.qpb;
     g.nqb = (int)(g.n_pad / g.qpb);
@@ -778,7 +782,8 @@ KnnGeometry knn_geometry(long long n, long long m, int d, int k, int splits) {
             const double dense = 1024.0 * kt;                  // rows over which every subtile has candidates
             const double entries = chunk <= dense ? sub : dense / 32.0 * (1.0 + log(chunk / dense));
             const double merges = 64.0 + kt * log(chunk / 64.0);
-            return sub * (g.D2 * 152.0) + entries * 2300.0 + merges * 4400.0;
+            // MFMA time of a subtile with nw/4 waves sharing each SIMD, at the measured no-selection efficiency
+            return sub * (g.D2 * 64.0 * (g.nw / 4) / 0.86) + entries * 2300.0 + merges * 4400.0;
         };
         long long s_max = (long long)rows_rt * g.RT / min_chunk;
         if (s_max > 64) s_max = 64;
@@ -839,9 +844,9 @@ hipError_t launch_pack(const float* X, long long n, int d, const KnnGeometry& g,
 hipError_t launch_fused(const KnnGeometry& g, const float* Qp, const float* Rp, const float* rnorm,
                         unsigned long long* lists, long long n, int kt, unsigned long long* diag,
                         hipStream_t stream) {
-#define SCMIAC_FUSED_CASE(V_, NW_, RT_)                                                            \
-    if (g.D2 == V_ && g.nw == NW_ && g.RT == RT_)                                                  \
-        return launch_fused_t<V_, NW_, RT_>(Qp, Rp, rnorm, lists, n, g.n_pad, g.nqb, g.S, g.chunk_rows, g.tail, kt, diag, stream);
+#define SCMIAC_FUSED_CASE(V_, NW_, RT_, PC_)                                                       \
+    if (g.D2 == V_ && g.nw == NW_ && g.RT == RT_ && g.pcap == PC_)                                 \
+        return launch_fused_t<V_, NW_, RT_, PC_>(Qp, Rp, rnorm, lists, n, g.n_pad, g.nqb, g.S, g.chunk_rows, g.tail, kt, diag, stream);
     SCMIAC_FUSED_VARIANTS(SCMIAC_FUSED_CASE)
     return hipErrorInvalidValue;
 #undef SCMIAC_FUSED_CASE

@@ -140,11 +140,12 @@ def test_knn_tail_region(monkeypatch):
     chunks each.  Forced at a small size by pretending the GPU runs 8 blocks at once."""
     monkeypatch.setenv("SCMIAC_FUSED_SLOTS", "8")
     monkeypatch.setenv("SCMIAC_FUSED_TAIL_MIN_ROWS", "1024")
-    Q = _mixture(61, 3000, 50)              # 12 query blocks: 8 + a tail of 4
+    Q = _mixture(61, 5000, 50)              # 14 query blocks of 384: 8 + a tail of 6
     R = _mixture(62, 20000, 50, offset=True)
     R[5000:5100] = R[3]                      # ties across tail chunks -> direct evaluation too
+    assert _hip.knn_grid_plan(3300, 20000, 50, 31)["St"] > 1
     _check_knn(Q, R, 30)
-    _check_knn(Q[:2100], R, 31)             # 9 blocks: tail of 1
+    _check_knn(Q[:3300], R, 31)             # 9 blocks: tail of 1
 
 
 def test_knn_distances_within_tolerance_of_float64():

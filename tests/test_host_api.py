@@ -96,23 +96,24 @@ def test_grid_plan(monkeypatch):
     are cut into more reference chunks so that the last round is short and full."""
     from scmiac_amd import _hip
 
-    # 256 compute units, one block each (what the library assumes when no GPU answers)
+    # 256 compute units, one 12-wave block (384 queries) each: what the library assumes
+    # when no GPU answers
     p = _hip.knn_grid_plan(1_000_000, 1_000_000, 50, 30)
-    assert p["query_blocks"] == 3907 and p["queries_per_block"] == 256
-    assert p["S"] == 1 and p["main_query_blocks"] == 3840 and p["St"] > 1
-    assert p["grid_blocks"] == 3840 + 67 * p["St"]
+    assert p["queries_per_block"] == 384 and p["query_blocks"] == 2605
+    assert p["S"] == 1 and p["main_query_blocks"] == 2560 and p["St"] > 1
+    assert p["grid_blocks"] == 2560 + 45 * p["St"]
     assert p["tail_chunk_rows"] * p["St"] >= 1_000_000
     # a whole number of rounds: nothing to cut
-    p = _hip.knn_grid_plan(262144, 1_000_000, 50, 30)
+    p = _hip.knn_grid_plan(393216, 1_000_000, 50, 30)
     assert p["S"] == 1 and p["main_query_blocks"] == 1024 and p["grid_blocks"] == 1024
     # few query blocks: all of them are cut, so that the grid still fills the GPU
     p = _hip.knn_grid_plan(10_000, 1_000_000, 50, 30)
-    assert p["main_query_blocks"] == 0 and p["grid_blocks"] == 40 * p["St"] >= 200
+    assert p["main_query_blocks"] == 0 and p["grid_blocks"] == 27 * p["St"] >= 200
     # an explicit number of chunks is taken as given
     p = _hip.knn_grid_plan(3000, 20000, 50, 30, splits=7)
-    assert p["S"] == 7 and p["main_query_blocks"] == 12 and p["grid_blocks"] == 84
+    assert p["S"] == 7 and p["main_query_blocks"] == 8 and p["grid_blocks"] == 56
     # test aid: a pretend 8-slot GPU makes small problems grow a tail
     monkeypatch.setenv("SCMIAC_FUSED_SLOTS", "8")
     monkeypatch.setenv("SCMIAC_FUSED_TAIL_MIN_ROWS", "1024")
-    p = _hip.knn_grid_plan(3000, 20000, 50, 30)
-    assert p["main_query_blocks"] in (8, 12) and p["grid_blocks"] >= 12
+    p = _hip.knn_grid_plan(3300, 20000, 50, 30)   # 9 query blocks: 8 + a tail of 1
+    assert p["main_query_blocks"] == 8 and p["St"] > 1 and p["grid_blocks"] == 8 + p["St"]
