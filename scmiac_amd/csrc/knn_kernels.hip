@@ -137,10 +137,10 @@ struct FusedCfg {
     static constexpr int RT = RT_;                     // reference rows per LDS stage
     static constexpr int NW = NW_;                     // waves per block
     static constexpr int PCAP = PCAP_;                 // pending candidates per query
+    static constexpr int NB = 2;                       // LDS stage buffers
     static constexpr int QPB = NW * 32;                // queries per block
     static constexpr size_t lds_bytes() {
-        return sizeof(float) * (2 * RT * LS + 2 * RT) + sizeof(uint2) * (NW * 32 * PCAP) +
-               sizeof(unsigned) * (NW * 32);
+        return sizeof(float) * (NB * RT * LS + NB * RT) + sizeof(uint2) * (NW * 32 * PCAP);
     }
 };
 
@@ -175,11 +175,16 @@ __device__ __forceinline__ float4 lds_read_b128(const float* p) {
 
 // Merge query q's pending candidates into its 64-entry shortlist (global memory),
 // all 64 lanes cooperating.  Returns the new threshold (key of the kt-th entry).
-__device__ __forceinline__ float flush_query(unsigned c, const uint2* pend_q, u64* list_q,
+// The pending candidates of a query sit in two buffers of HCAP entries, one per lane half
+// of the MFMA layout (c0 and c1 entries in use).
+template <int HCAP>
+__device__ __forceinline__ float flush_query(unsigned c0, unsigned c1, const uint2* pend_q, u64* list_q,
                                              bool inited, int lane, int kt) {
+    static_assert(2 * HCAP <= 32, "both buffers are sorted by one 32-lane bitonic network");
     u64 key = LIST_SENTINEL;
-    if ((unsigned)lane < c) {
-        uint2 e = pend_q[lane];
+    const unsigned h = (unsigned)lane / HCAP, i = (unsigned)lane % HCAP;
+    if (h < 2u && i < (h ? c1 : c0)) {
+        uint2 e = pend_q[lane];  // buffer h, entry i
         key = ((u64)f2ord(__uint_as_float(e.x)) << 32) | (u64)e.y;
     }
     key = wave_sort<32>(key, lane);  // lanes 0..31 ascending, 32..63 all sentinel
@@ -195,17 +200,18 @@ __device__ __forceinline__ float flush_query(unsigned c, const uint2* pend_q, u6
     return ord2f(top);
 }
 
-template <int D2, int NW_, int RT_, int PCAP_>
+template <int D2, int NW_, int RT_, int PCAP_, bool DIAG_>
 __global__ __launch_bounds__(NW_ * 64, (NW_ >= 8 ? NW_ / 4 : 2)) void fused_knn_kernel(
     const float* __restrict__ Qp,     // [n_pad][ROWF], already scaled by -2
     const float* __restrict__ Rp,     // [m_pad][LS], zero pad columns
     const float* __restrict__ rnorm,  // [m_pad], 1.7e38 on padding rows
     u64* __restrict__ lists,          // [S][n_pad][64], then the tail region's extra lists
     long long n, long long n_pad, int nqb, long long chunk_rows, FusedTail tail, int kt, int ablate,
-    u64* __restrict__ diag /* per wave 8 counters, or NULL (diagnostic runs only) */) {
+    u64* __restrict__ diag_out /* per wave 8 counters (DIAG_ instantiations only) */) {
+    u64* const diag = DIAG_ ? diag_out : nullptr;  // compile-time NULL in the product kernel
     using C = FusedCfg<D2, NW_, RT_, PCAP_>;
     constexpr int D2P = C::D2P, ROWF = C::ROWF, LS = C::LS, RT = C::RT, NW = C::NW;
-    constexpr int PCAP = C::PCAP, NSUB = RT / 32;
+    constexpr int PCAP = C::PCAP, NSUB = RT / 32, NB = C::NB;
     constexpr int STAGE_BYTES = RT * LS * 4;
     constexpr int NCHUNK = STAGE_BYTES / 1024;  // 1 KiB = one wave-wide 16-byte LDS-DMA load
     constexpr int LD_ITERS = (NCHUNK + NW - 1) / NW;
@@ -216,10 +222,9 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ >= 8 ? NW_ / 4 : 2)) void fused_knn_
     (void)ROWF;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* tile = reinterpret_cast<float*>(smem);           // [2][RT*LS]
-    float* tnorm = tile + 2 * RT * LS;                      // [2][RT]
-    uint2* pend = reinterpret_cast<uint2*>(tnorm + 2 * RT);  // [NW][32][PCAP]
-    unsigned* cnt = reinterpret_cast<unsigned*>(pend + NW * 32 * PCAP);  // [NW][32]
+    float* tile = reinterpret_cast<float*>(smem);             // [NB][RT*LS]
+    float* tnorm = tile + NB * RT * LS;                       // [NB][RT]
+    uint2* pend = reinterpret_cast<uint2*>(tnorm + NB * RT);  // [NW][32][PCAP]
     const unsigned tile_lds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)tile;
     const unsigned tnorm_lds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)tnorm;
 
@@ -251,8 +256,10 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ >= 8 ? NW_ / 4 : 2)) void fused_knn_
     const long long q0 = (long long)qb * C::QPB + wave * 32;  // first query of this wave
     const int T = (int)(rows_here / RT);
 
+    constexpr int HCAP = PCAP / 2;  // each lane appends to a buffer of its own: no atomics
     uint2* pend_w = pend + wave * 32 * PCAP;
-    unsigned* cnt_w = cnt + wave * 32;
+    uint2* pend_l = pend_w + (j * 2 + hh) * HCAP;  // this lane's buffer: query j, lane half hh
+    unsigned pcnt = 0u;                            // entries in it
     u64* lists_w = lists + list_row * 64;
 
     // B operand: this lane's query features, one register per MFMA step
@@ -272,7 +279,12 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ >= 8 ? NW_ / 4 : 2)) void fused_knn_
     // running threshold: score of the 64th best reference so far; padding queries take nothing
     const float tau_max = __uint_as_float(TAU_MAX_BITS);  // padding rows score exactly this
     float tau = (q0 + j < n && !(ablate & 1)) ? tau_max : -__builtin_inff();
-    if (lane < 32) cnt_w[lane] = 0u;
+    // The per-subtile test looks at raw scores; a key is within 16 ulp (2^-19 relative) of
+    // its score, so "some key below tau" implies "some score below tau_hi".
+    auto widen = [](float t) __attribute__((always_inline)) {
+        return t > -__builtin_inff() ? t + fabsf(t) * 3.814697265625e-06f + 1e-30f : t;  // 2^-18 relative
+    };
+    float tau_hi = widen(tau);
     unsigned inited = 0u;  // bit q: query q's shortlist exists in global memory (wave-uniform)
 
     // Stage copy global -> LDS without registers: RT packed rows are one contiguous byte
@@ -293,75 +305,110 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ >= 8 ? NW_ / 4 : 2)) void fused_knn_
     u64 dg_slow = 0, dg_flush = 0, dg_nslow = 0, dg_nflush = 0, dg_npush = 0, dg_iters = 0;
     const u64 dg_t0 = diag ? (u64)clock64() : 0;
 
-    // merge every query of this wave whose pending count is >= min_cnt (or, at the end,
-    // that has no shortlist in memory yet)
-    auto flush_full = [&](unsigned min_cnt, bool force_uninit) __attribute__((always_inline)) {
+    // merge every query of this wave that has a full buffer (only_full) or any pending
+    // candidate, or, at the end, no shortlist in memory yet
+    auto flush_full = [&](bool only_full, bool force_uninit) __attribute__((always_inline)) {
         const u64 tf0 = diag ? (u64)clock64() : 0;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        unsigned c = cnt_w[j];
-        bool need = (c >= min_cnt) || (force_uninit && !((inited >> j) & 1u) && (q0 + j < n));
-        u64 mask = __ballot(need) & 0xffffffffull;
+        bool need = only_full ? (pcnt >= (unsigned)HCAP) : (pcnt > 0u);
+        need = need || (force_uninit && !((inited >> j) & 1u) && (q0 + j < n));
+        const u64 m64 = __ballot(need);
+        u64 mask = (m64 | (m64 >> 32)) & 0xffffffffull;
         while (mask) {
             int q = __builtin_ctzll(mask);
             mask &= mask - 1;
-            unsigned cq = __builtin_amdgcn_readlane(c, q);
-            cq = cq > (unsigned)PCAP ? (unsigned)PCAP : cq;
-            float nt = flush_query(cq, pend_w + q * PCAP, lists_w + (long long)q * 64,
-                                   (inited >> q) & 1u, lane, kt);
+            const unsigned c0 = __builtin_amdgcn_readlane(pcnt, q);
+            const unsigned c1 = __builtin_amdgcn_readlane(pcnt, q + 32);
+            float nt = flush_query<HCAP>(c0, c1, pend_w + q * PCAP, lists_w + (long long)q * 64,
+                                         (inited >> q) & 1u, lane, kt);
             inited |= 1u << q;
-            if (j == q) tau = fminf(nt, tau_max);
-            if (lane == 0) cnt_w[q] = 0u;
+            if (j == q) { tau = fminf(nt, tau_max); tau_hi = widen(tau); pcnt = 0u; }
             if (diag) ++dg_nflush;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (diag) dg_flush += (u64)clock64() - tf0;
     };
 
-    // Candidate path (entered when some lane's smallest key is below its threshold).
-    // Each lane walks its keys in ascending order: store the current one (one LDS atomic
-    // for the slot), then advance to the next greater key; a lane whose buffer is full
-    // waits for the merge and retries the same key against the new threshold.
-    auto select_slow = [&](const float (&key)[16], float kmin, unsigned ref0) __attribute__((always_inline)) {
+    // Candidate path (entered when some lane's smallest score is below its threshold).
+    // Register by register: the lanes whose key passes append it to their own buffer.  Every
+    // step that depends on the one before costs a wave hundreds of cycles while its SIMD
+    // partners keep the MFMA pipe busy, so the path is kept shallow: no cross-lane
+    // traffic, no atomics, no search for minima.
+    auto select_slow = [&](const f32x16& acc, unsigned ref0) __attribute__((always_inline)) {
         const u64 ts0 = diag ? (u64)clock64() : 0;
         if (diag) ++dg_nslow;
         if (ablate & 8) {  // diagnostic: price of reaching this path and returning
             if (diag) dg_slow += (u64)clock64() - ts0;
             return;
         }
-        __builtin_amdgcn_s_setprio(2);  // finish this short scalar/vector stretch ahead of the SIMD partner
-        float cur = kmin;
-        bool pass = cur < tau;
-        do {
-            if (diag) ++dg_iters;
-            unsigned slot = (unsigned)PCAP;
-            if (pass) slot = atomicAdd(&cnt_w[j], 1u);
-            // while the slot is on its way: this lane's next key in ascending order
-            float gt[16];
+        // (the empty statement keeps the compiler from hoisting this path's arithmetic above
+        // the branch that guards it, into the per-subtile code every wave runs)
+        f32x16 sc = acc;
+        asm volatile("" : "+v"(sc));
+        float key[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) gt[r] = (key[r] > cur) ? key[r] : __builtin_inff();
-            float nxt = fminf(fminf(gt[0], gt[1]), gt[2]);
+        for (int r = 0; r < 16; ++r) key[r] = score_key(sc[r], r);
+        // smallest key of the lane, as a depth-3 tree (every dependent step costs a turn)
+        const float a0 = fminf(fminf(key[0], key[1]), key[2]), a1 = fminf(fminf(key[3], key[4]), key[5]);
+        const float a2 = fminf(fminf(key[6], key[7]), key[8]), a3 = fminf(fminf(key[9], key[10]), key[11]);
+        const float a4 = fminf(fminf(key[12], key[13]), key[14]);
+        const float kmin = fminf(fminf(fminf(a0, a1), a2), fminf(fminf(a3, a4), key[15]));
+        // does any lane have two keys below its threshold?  (scalar bookkeeping on the masks)
+        u64 seen = 0ull, twice = 0ull;
 #pragma unroll
-            for (int r = 3; r < 15; r += 2) nxt = fminf(fminf(nxt, gt[r]), gt[r + 1]);
-            nxt = fminf(nxt, gt[15]);
-            const bool stored = pass && slot < (unsigned)PCAP;
-            if (stored) {
-                const unsigned r = __float_as_uint(cur) & 15u;
-                pend_w[j * PCAP + slot] = make_uint2(__float_as_uint(cur), ref0 + (r & 3u) + 8u * (r >> 2));
+        for (int r = 0; r < 16; ++r) {
+            const u64 m = __ballot(key[r] < tau);
+            twice |= seen & m;
+            seen |= m;
+        }
+        if (ablate & 16) {  // diagnostic: price of the arithmetic above without any store
+            asm volatile("" ::"v"(kmin), "s"(twice));
+            return;
+        }
+        if (twice == 0ull) {
+            // the usual case: at most one candidate per lane, and it is the lane's smallest key
+            const bool p = kmin < tau;
+            if (__any(p && pcnt >= (unsigned)HCAP)) flush_full(true, false);
+            if (p && kmin < tau) {
+                const unsigned kb = __float_as_uint(kmin);
+                // key register r holds subtile row (r & 3) + 8 (r >> 2) = r + (r & 12)
+                if (!(ablate & 32))  // diagnostic: everything but the store itself
+                    pend_l[pcnt] = make_uint2(kb, ref0 + (kb & 15u) + (kb & 12u));
+                ++pcnt;
             }
-            if (diag) dg_npush += __popcll(__ballot(stored));
-            if (__any(pass && !stored)) {  // a buffer is full: merge, thresholds tighten
-                flush_full((unsigned)PCAP, false);
+            if (diag) { ++dg_iters; dg_npush += __popcll(__ballot(p)); }
+        } else {
+            unsigned skipped = 0u;  // bit r: key[r] passed but this lane's buffer was full
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const bool p = key[r] < tau;
+                if (__any(p)) {
+                    const bool room = pcnt < (unsigned)HCAP;
+                    if (p && room) {
+                        pend_l[pcnt] = make_uint2(__float_as_uint(key[r]), ref0 + (unsigned)((r & 3) + 8 * (r >> 2)));
+                        ++pcnt;
+                    }
+                    if (p && !room) skipped |= 1u << r;
+                    if (diag) { ++dg_iters; dg_npush += __popcll(__ballot(p && room)); }
+                }
             }
-            cur = stored ? nxt : cur;  // a lane that could not store retries the same key
-            pass = cur < tau;
-        } while (__any(pass));
-        __builtin_amdgcn_s_setprio(0);
+            if (__any(skipped != 0u)) {  // merge the full buffers, then the keys left over
+                flush_full(true, false);  // (an emptied buffer takes all 16 keys of a lane)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool p = ((skipped >> r) & 1u) && key[r] < tau;  // against the tightened threshold
+                    if (__any(p)) {
+                        if (p) {
+                            pend_l[pcnt] = make_uint2(__float_as_uint(key[r]), ref0 + (unsigned)((r & 3) + 8 * (r >> 2)));
+                            ++pcnt;
+                        }
+                        if (diag) { ++dg_iters; dg_npush += __popcll(__ballot(p)); }
+                    }
+                }
+            }
+        }
         if (diag) dg_slow += (u64)clock64() - ts0;
     };
-
-    if (T > 0) SCMIAC_STAGE(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
 
     // Software pipeline over subtiles (32 references each).  While the MFMA chain of
     // subtile s runs, the wave issues the threshold test of subtile s-1 (other
@@ -396,41 +443,42 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ >= 8 ? NW_ / 4 : 2)) void fused_knn_
         _Pragma("unroll") for (int s = 0; s < HEAD; ++s)                                            \
             accs[CUR_] = __builtin_amdgcn_mfma_f32_32x32x2f32(rfr[CUR_][s], qf[s], accs[CUR_], 0, 0, 0); \
         if ((SUB_) + 1 < NSUB) SCMIAC_LOAD_FRAGS(rfr[PRV_], tb, (SUB_) + 1);                        \
-        float key_[16];                                                                             \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) key_[r] = score_key(accs[PRV_][r], r);       \
-        float mn_ = fminf(fminf(key_[0], key_[1]), key_[2]);                                        \
-        _Pragma("unroll") for (int r = 3; r < 15; r += 2) mn_ = fminf(fminf(mn_, key_[r]), key_[r + 1]); \
-        mn_ = fminf(mn_, key_[15]);                                                                 \
+        float mn_ = fminf(fminf(accs[PRV_][0], accs[PRV_][1]), accs[PRV_][2]);                      \
+        _Pragma("unroll") for (int r = 3; r < 15; r += 2)                                           \
+            mn_ = fminf(fminf(mn_, accs[PRV_][r]), accs[PRV_][r + 1]);                              \
+        mn_ = fminf(mn_, accs[PRV_][15]);                                                           \
         _Pragma("unroll") for (int s = HEAD; s < D2; ++s)                                           \
             accs[CUR_] = __builtin_amdgcn_mfma_f32_32x32x2f32(rfr[CUR_][s], qf[s], accs[CUR_], 0, 0, 0); \
         ref0s[CUR_] = (unsigned)(r_begin + (long long)t * RT + (SUB_) * 32 + 4 * hh);               \
-        if (__any(mn_ < tau)) select_slow(key_, mn_, ref0s[PRV_]);                                  \
+        if (__any(mn_ < tau_hi)) select_slow(accs[PRV_], ref0s[PRV_]);                              \
     } while (0)
 
-    for (int t = 0; t < T; ++t) {
-        if (do_stage && t + 1 < T) SCMIAC_STAGE(t + 1, (t + 1) & 1);
-        const float* tb = tile + (do_stage ? (t & 1) : 0) * RT * LS;
-        const float* nb = tnorm + (do_stage ? (t & 1) : 0) * RT;
-        // fragments of the stage's first subtile (the stage only became readable at the barrier)
-        SCMIAC_LOAD_FRAGS(rfr[0], tb, 0);
+    {   // Two stage buffers, one block barrier per stage.
+        if (T > 0) SCMIAC_STAGE(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int t = 0; t < T; ++t) {
+            if (do_stage && t + 1 < T) SCMIAC_STAGE(t + 1, (t + 1) & 1);
+            const float* tb = tile + (do_stage ? (t & 1) : 0) * RT * LS;
+            const float* nb = tnorm + (do_stage ? (t & 1) : 0) * RT;
+            // fragments of the stage's first subtile (the stage only became readable at the barrier)
+            SCMIAC_LOAD_FRAGS(rfr[0], tb, 0);
 #pragma unroll
-        for (int sp = 0; sp < NSUB; sp += 2) {
-            SCMIAC_SUBTILE(0, 1, sp);
-            SCMIAC_SUBTILE(1, 0, sp + 1);
+            for (int sp = 0; sp < NSUB; sp += 2) {
+                SCMIAC_SUBTILE(0, 1, sp);
+                SCMIAC_SUBTILE(1, 0, sp + 1);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA loads have landed
+            if (do_sync) __syncthreads();
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA loads have landed
-        if (do_sync) __syncthreads();
     }
     if (T > 0) {  // the last subtile is still untested
-        float key_[16];
+        float mn_ = accs[1][0];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) key_[r] = score_key(accs[1][r], r);
-        float mn_ = key_[0];
-#pragma unroll
-        for (int r = 1; r < 16; ++r) mn_ = fminf(mn_, key_[r]);
-        if (__any(mn_ < tau)) select_slow(key_, mn_, ref0s[1]);
+        for (int r = 1; r < 16; ++r) mn_ = fminf(mn_, accs[1][r]);
+        if (__any(mn_ < tau_hi)) select_slow(accs[1], ref0s[1]);
     }
-    flush_full(1u, true);
+    flush_full(false, true);
     if (diag && lane == 0) {
         u64* o = diag + ((long long)blockIdx.x * NW + wave) * 8;
         o[0] = (u64)clock64() - dg_t0; o[1] = dg_slow; o[2] = dg_flush; o[3] = dg_nslow;
@@ -460,7 +508,8 @@ __global__ __launch_bounds__(256) void refine_kernel(
     const u64* __restrict__ lists, int S, FusedTail tail, int k, int kt, long long col_offset, int merge,
     double err_abs_coef,  // 2*G: |s + |q|^2 - T| <= err_abs_coef * (|r|^2 + |q|^2)
     double rel_keep,      // 1 - gamma: D >= T * rel_keep
-    const unsigned* __restrict__ maxnorm_bits, int* __restrict__ out_idx,
+    const unsigned* __restrict__ maxnorm_bits,
+    int* __restrict__ out_idx,
     float* __restrict__ out_d2, float* __restrict__ out_dist, double* __restrict__ lower_bound,
     int* __restrict__ fail_rows, int* __restrict__ n_fail) {
     const int lane = threadIdx.x & 63;
@@ -672,7 +721,7 @@ static const int kD2Sizes[] = {8, 15, 16, 20, 25, 32, 40, 50, 64};
 #define SCMIAC_FUSED_VARIANTS(X) \
     X(8, 12, 128, 32) X(15, 12, 128, 32) X(16, 12, 128, 32) X(20, 12, 128, 32) X(25, 12, 128, 32) \
     X(32, 8, 128, 32) X(40, 8, 64, 32) X(50, 8, 64, 32) X(64, 8, 64, 32) \
-    X(25, 8, 128, 32) X(25, 16, 128, 16) X(32, 12, 64, 32)
+    X(25, 8, 128, 32) X(32, 12, 64, 32)
 
 int knn_pick_d2(int d) {
     int need = (d + 1) / 2;
@@ -681,19 +730,19 @@ int knn_pick_d2(int d) {
     return -1;
 }
 
-template <int D2, int NW, int RT, int PC>
+template <int D2, int NW, int RT, int PC, bool DIAG>
 static hipError_t launch_fused_t(const float* Qp, const float* Rp, const float* rnorm, u64* lists,
                                  long long n, long long n_pad, int nqb, int S, long long chunk_rows,
                                  const FusedTail& tail, int kt, u64* diag, hipStream_t stream) {
     using C = FusedCfg<D2, NW, RT, PC>;
     size_t lds = C::lds_bytes();
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_knn_kernel<D2, NW, RT, PC>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_knn_kernel<D2, NW, RT, PC, DIAG>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     dim3 grid((unsigned)(tail.block0 + (nqb - tail.qb0) * tail.St)), block(NW * 64);
     int ablate = 0;
     if (const char* v = getenv("SCMIAC_FUSED_ABLATE")) ablate = atoi(v);  // diagnostic builds only
-    hipLaunchKernelGGL((fused_knn_kernel<D2, NW, RT, PC>), grid, block, lds, stream, Qp, Rp, rnorm, lists, n,
+    hipLaunchKernelGGL((fused_knn_kernel<D2, NW, RT, PC, DIAG>), grid, block, lds, stream, Qp, Rp, rnorm, lists, n,
                        n_pad, nqb, chunk_rows, tail, kt, ablate, diag);
     return hipGetLastError();
 }
@@ -704,7 +753,7 @@ static void fused_variant(int D2, int* nw, int* rt, int* pcap) {
     *nw = (D2 <= 25) ? 12 : 8;
     *rt = (D2 <= 32) ? 128 : 64;
     *pcap = 32;
-    if (const char* v = getenv("SCMIAC_FUSED_VARIANT")) {  // tuning aid: "NWxRTxPCAP", e.g. 12x128x16
+    if (const char* v = getenv("SCMIAC_FUSED_VARIANT")) {  // tuning aid: "NWxRTxPCAP", e.g. 8x128x32
         int a = 0, b = 0, c = 32;
         if (sscanf(v, "%dx%dx%d", &a, &b, &c) >= 2 && (D2 == 25 || D2 == 32)) { *nw = a; *rt = b; *pcap = c; }
     }
@@ -713,6 +762,7 @@ static void fused_variant(int D2, int* nw, int* rt, int* pcap) {
 // blocks of the fused kernel the GPU runs at once (256 one-block CUs when no device answers)
 template <int D2, int NW, int RT, int PC>
 static int fused_occupancy_t() {
+    constexpr bool DIAG = false;
     using C = FusedCfg<D2, NW, RT, PC>;
     int dev = 0, cus = 0, per_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
@@ -720,9 +770,9 @@ static int fused_occupancy_t() {
         (void)hipGetLastError();
         return 256;
     }
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_knn_kernel<D2, NW, RT, PC>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_knn_kernel<D2, NW, RT, PC, DIAG>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes());
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_knn_kernel<D2, NW, RT, PC>, NW * 64,
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_knn_kernel<D2, NW, RT, PC, DIAG>, NW * 64,
                                                      C::lds_bytes()) != hipSuccess || per_cu <= 0) {
         (void)hipGetLastError();
         per_cu = 1;
@@ -846,7 +896,8 @@ hipError_t launch_fused(const KnnGeometry& g, const float* Qp, const float* Rp, 
                         hipStream_t stream) {
 #define SCMIAC_FUSED_CASE(V_, NW_, RT_, PC_)                                                       \
     if (g.D2 == V_ && g.nw == NW_ && g.RT == RT_ && g.pcap == PC_)                                 \
-        return launch_fused_t<V_, NW_, RT_, PC_>(Qp, Rp, rnorm, lists, n, g.n_pad, g.nqb, g.S, g.chunk_rows, g.tail, kt, diag, stream);
+        return diag ? launch_fused_t<V_, NW_, RT_, PC_, true>(Qp, Rp, rnorm, lists, n, g.n_pad, g.nqb, g.S, g.chunk_rows, g.tail, kt, diag, stream) \
+                    : launch_fused_t<V_, NW_, RT_, PC_, false>(Qp, Rp, rnorm, lists, n, g.n_pad, g.nqb, g.S, g.chunk_rows, g.tail, kt, diag, stream);
     SCMIAC_FUSED_VARIANTS(SCMIAC_FUSED_CASE)
     return hipErrorInvalidValue;
 #undef SCMIAC_FUSED_CASE

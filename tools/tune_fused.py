@@ -35,7 +35,9 @@ def main():
         for v in args.variants:
             os.environ["SCMIAC_FUSED_VARIANT"] = v
             _hip.set_timing(True)
-            st = _hip.knn_search(q, r, args.k, splits=args.splits)
+            # ablated kernels leave poor shortlists: skip the direct-evaluation pass they would trigger
+            ablated = os.environ.get("SCMIAC_FUSED_ABLATE", "0") != "0"
+            st = _hip.knn_search(q, r, args.k, splits=args.splits, exact_fallback=not ablated)
             ms, cnt = _hip.fused_ms()
             _hip.set_timing(False)
             if os.environ.get("SCMIAC_FUSED_ABLATE", "0") != "0":
