@@ -46,7 +46,11 @@ WORKLOADS = {
     "c3": (1_000_000, 1_000_000, 50, 100, (2000, 2001, 2002)),
     "c2": (100_000, 100_000, 50, 50, (1000, 1001, 1002)),
     "small": (20_000, 20_000, 50, 20, (900, 901, 902)),
+    # one GPU's share of the 4M x 2M, d=64 cosine atlas on 8 GPUs: its 500k query rows against all 2M
+    # reference rows (what the ring delivers block by block); rows L2-normalised, so Euclidean = cosine order
+    "c5shard": (500_000, 2_000_000, 64, 200, (5000, 5001, 5002)),
 }
+UNIT_NORM = {"c5shard"}
 
 
 def make_latents(name, n=None, m=None):
@@ -62,6 +66,9 @@ def make_latents(name, n=None, m=None):
     U = centres[l1] + rr.standard_normal((n, d), dtype=np.float32)
     l2 = ra.integers(0, C, m)
     V = centres[l2] + offset + ra.standard_normal((m, d), dtype=np.float32)
+    if name in UNIT_NORM:
+        U /= np.linalg.norm(U, axis=1, keepdims=True)
+        V /= np.linalg.norm(V, axis=1, keepdims=True)
     return U, V, l1.astype(np.int32), l2.astype(np.int32), d
 
 

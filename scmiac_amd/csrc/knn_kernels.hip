@@ -721,7 +721,7 @@ static const int kD2Sizes[] = {8, 15, 16, 20, 25, 32, 40, 50, 64};
 #define SCMIAC_FUSED_VARIANTS(X) \
     X(8, 12, 128, 32) X(15, 12, 128, 32) X(16, 12, 128, 32) X(20, 12, 128, 32) X(25, 12, 128, 32) \
     X(32, 8, 128, 32) X(40, 8, 64, 32) X(50, 8, 64, 32) X(64, 8, 64, 32) \
-    X(25, 8, 128, 32) X(32, 12, 64, 32)
+    X(25, 8, 128, 32) X(32, 12, 64, 32) X(32, 12, 128, 24)
 
 int knn_pick_d2(int d) {
     int need = (d + 1) / 2;
@@ -750,9 +750,9 @@ static hipError_t launch_fused_t(const float* Qp, const float* Rp, const float* 
 // (waves per block, reference rows per LDS stage) of the fused kernel
 static void fused_variant(int D2, int* nw, int* rt, int* pcap) {
     // 12 waves (3 per SIMD) where the candidate buffers and two stages fit the 160 KiB of LDS
-    *nw = (D2 <= 25) ? 12 : 8;
+    *nw = (D2 <= 32) ? 12 : 8;
     *rt = (D2 <= 32) ? 128 : 64;
-    *pcap = 32;
+    *pcap = (D2 == 32) ? 24 : 32;  // 64 features: shorter candidate buffers make room for the wider stages
     if (const char* v = getenv("SCMIAC_FUSED_VARIANT")) {  // tuning aid: "NWxRTxPCAP", e.g. 8x128x32
         int a = 0, b = 0, c = 32;
         if (sscanf(v, "%dx%dx%d", &a, &b, &c) >= 2 && (D2 == 25 || D2 == 32)) { *nw = a; *rt = b; *pcap = c; }

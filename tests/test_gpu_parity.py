@@ -316,3 +316,27 @@ def test_large_search_sampled_against_oracle():
     idx_o, d2_o = oracle.knn_dist2(Q[rows].cpu().numpy(), R.cpu().numpy(), 30)
     np.testing.assert_array_equal(st.idx[rows].cpu().numpy(), idx_o)
     np.testing.assert_array_equal(st.dist2[rows].cpu().numpy(), d2_o)
+
+
+def test_ring_search_unit_norm_d64_single_rank(tmp_path):
+    """Ring mode with the real kernels (one rank: the transport is covered by the gloo
+    tests): L2-normalised d=64 latents, duplicates that force the direct-evaluation trip."""
+    import torch.distributed as dist
+    from scmiac_amd import sharded
+
+    Q = _mixture(71, 2000, 64, unit=True)
+    R = _mixture(72, 30000, 64, unit=True, offset=True)
+    R[1000:1200] = R[5]  # 200 copies: ties beyond the shortlist
+    Q[:20] = R[5]
+    dist.init_process_group("nccl", init_method=f"file://{tmp_path}/rdzv", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        st = sharded.knn_ring(_dev(Q), _dev(R), 30)
+        torch.cuda.synchronize()
+        full = sharded.gather_rows(st.idx, len(Q))
+    finally:
+        dist.destroy_process_group()
+    idx_o, d2_o = oracle.knn_dist2(Q, R, 30)
+    np.testing.assert_array_equal(full.cpu().numpy(), idx_o)
+    np.testing.assert_array_equal(st.dist2.cpu().numpy(), d2_o)
+    assert int(st.n_uncertified.item()) > 0

@@ -25,9 +25,10 @@ def main():
     ap.add_argument("--k", type=int, default=30)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--splits", type=int, default=0)
-    ap.add_argument("--variants", nargs="+", default=["8x128"])
+    ap.add_argument("--variants", nargs="+", default=["12x128x32"])
+    ap.add_argument("--workload", default="c3", help="bench.py workload the latents are drawn from")
     args = ap.parse_args()
-    U, V, _, _, d = bench.make_latents("c3", args.n, args.m)
+    U, V, _, _, d = bench.make_latents(args.workload, args.n, args.m)
     q, r = torch.from_numpy(U).cuda(), torch.from_numpy(V).cuda()
     res = {v: [] for v in args.variants}
     ref_idx = None
