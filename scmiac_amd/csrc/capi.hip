@@ -157,7 +157,7 @@ int scmiac_knn_search(const float* q, int64_t n, const float* r, int64_t m, int 
         HIP_TRY(hipEventRecord(g_ev1[g_ev_used], stream), "event record");
         ++g_ev_used;
     }
-    HIP_TRY(launch_refine(q, r, d, n, g, w.lists, k, knn_threshold_rank(k), col_offset, merge, w.maxnorm, idx, dist2, dist,
+    HIP_TRY(launch_refine(q, w.qp, w.rp, d, n, g, w.lists, k, knn_threshold_rank(k), col_offset, merge, w.maxnorm, idx, dist2, dist,
                           lower_bound, uncertified_rows, n_uncertified, stream),
             "refine");
     if (exact_fallback)  // the shortlists are dead once refine has run: their memory is the scratch

@@ -54,7 +54,7 @@ hipError_t launch_pack(const float* X, long long n, int d, const KnnGeometry& g,
 hipError_t launch_fused(const KnnGeometry& g, const float* Qp, const float* Rp, const float* rnorm,
                         unsigned long long* lists, long long n, int kt, unsigned long long* diag,
                         hipStream_t stream);
-hipError_t launch_refine(const float* Q, const float* R, int d, long long n, const KnnGeometry& g,
+hipError_t launch_refine(const float* Q, const float* Qp, const float* Rp, int d, long long n, const KnnGeometry& g,
                          const unsigned long long* lists, int k, int kt, long long col_offset, int merge,
                          const unsigned* maxnorm_bits, int* idx, float* d2, float* dist, double* lb,
                          int* fail_rows, int* n_fail, hipStream_t stream);

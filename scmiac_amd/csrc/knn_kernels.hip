@@ -503,8 +503,25 @@ __device__ __forceinline__ float exact_dist2(const float* __restrict__ a, const 
     return acc;
 }
 
+// Exact squared distance from the packed copies (16-byte loads): the packed order is the
+// feature order with zeros in between, and a zero pair leaves the fmaf chain's value as it
+// is, so this is bit-identical to exact_dist2 on the original rows.  qp holds -2 q.
+__device__ __forceinline__ float exact_dist2_packed(const float4* __restrict__ qp, const float4* __restrict__ rp,
+                                                    int chunks) {
+    float acc = 0.0f;
+    for (int c = 0; c < chunks; ++c) {
+        const float4 a = qp[c], b = rp[c];
+        float t = __fsub_rn(-0.5f * a.x, b.x); acc = __fmaf_rn(t, t, acc);
+        t = __fsub_rn(-0.5f * a.y, b.y); acc = __fmaf_rn(t, t, acc);
+        t = __fsub_rn(-0.5f * a.z, b.z); acc = __fmaf_rn(t, t, acc);
+        t = __fsub_rn(-0.5f * a.w, b.w); acc = __fmaf_rn(t, t, acc);
+    }
+    return acc;
+}
+
 __global__ __launch_bounds__(256) void refine_kernel(
-    const float* __restrict__ Q, const float* __restrict__ R, int d, long long n, long long n_pad,
+    const float* __restrict__ Q, const float* __restrict__ Qp, const float* __restrict__ Rp, int rowf, int ls,
+    int d, long long n, long long n_pad,
     const u64* __restrict__ lists, int S, FusedTail tail, int k, int kt, long long col_offset, int merge,
     double err_abs_coef,  // 2*G: |s + |q|^2 - T| <= err_abs_coef * (|r|^2 + |q|^2)
     double rel_keep,      // 1 - gamma: D >= T * rel_keep
@@ -542,7 +559,8 @@ __global__ __launch_bounds__(256) void refine_kernel(
         float tau_s = ord2f(__builtin_amdgcn_readlane((unsigned)(e >> 32), kt - 1));
         u64 key = KEY_SENTINEL;
         if (ridx != 0xffffffffu) {
-            float D = exact_dist2(qrow, R + (long long)ridx * d, d);
+            float D = exact_dist2_packed(reinterpret_cast<const float4*>(Qp + q * rowf),
+                                         reinterpret_cast<const float4*>(Rp + (long long)ridx * ls), rowf / 4);
             key = ((u64)__float_as_uint(D) << 32) | (u64)(unsigned)(ridx + col_offset);
         }
         key = wave_sort<64>(key, lane);
@@ -903,7 +921,7 @@ hipError_t launch_fused(const KnnGeometry& g, const float* Qp, const float* Rp, 
 #undef SCMIAC_FUSED_CASE
 }
 
-hipError_t launch_refine(const float* Q, const float* R, int d, long long n, const KnnGeometry& g,
+hipError_t launch_refine(const float* Q, const float* Qp, const float* Rp, int d, long long n, const KnnGeometry& g,
                          const unsigned long long* lists, int k, int kt, long long col_offset, int merge,
                          const unsigned* maxnorm_bits, int* idx, float* d2, float* dist, double* lb,
                          int* fail_rows, int* n_fail, hipStream_t stream) {
@@ -917,7 +935,7 @@ hipError_t launch_refine(const float* Q, const float* R, int d, long long n, con
     double err_abs_coef = 2.0 * G;
     double rel_keep = 1.0 - 2.0 * (double)(d + 4) * u;
     dim3 block(256), grid((unsigned)((n + 3) / 4));
-    hipLaunchKernelGGL(refine_kernel, grid, block, 0, stream, Q, R, d, n, g.n_pad, lists, g.S, g.tail, k, kt,
+    hipLaunchKernelGGL(refine_kernel, grid, block, 0, stream, Q, Qp, Rp, g.rowf, g.ls, d, n, g.n_pad, lists, g.S, g.tail, k, kt,
                        col_offset, merge, err_abs_coef, rel_keep, maxnorm_bits, idx, d2, dist, lb,
                        fail_rows, n_fail);
     return hipGetLastError();
