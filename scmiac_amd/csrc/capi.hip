@@ -35,6 +35,7 @@ struct KnnWs {
     float* rp;
     float* rnorm;
     unsigned long long* lists;
+    void* pend;  // pending-candidate buffers, when the fused kernel keeps them in global memory
     unsigned* maxnorm;
     unsigned long long* diag;  // per-wave counters of the fused kernel (diagnostic runs)
     size_t diag_offset, diag_bytes;
@@ -53,6 +54,8 @@ static KnnWs knn_carve(void* ws, long long n, const KnnGeometry& g) {
     off += up256(sizeof(float) * (size_t)g.m_pad);
     w.lists = reinterpret_cast<unsigned long long*>(p + off);
     off += up256(sizeof(unsigned long long) * (size_t)g.list_rows * 64);
+    w.pend = p + off;
+    if (g.gp) off += up256(8 * (size_t)g.list_rows * g.pcap);
     w.maxnorm = reinterpret_cast<unsigned*>(p + off);
     off += 256;
     w.diag = reinterpret_cast<unsigned long long*>(p + off);
@@ -151,7 +154,7 @@ int scmiac_knn_search(const float* q, int64_t n, const float* r, int64_t m, int 
         HIP_TRY(hipEventRecord(g_ev0[g_ev_used], stream), "event record");
     }
     const char* dg = getenv("SCMIAC_FUSED_DIAG");  // diagnostic runs: per-wave cycle counters
-    HIP_TRY(launch_fused(g, w.qp, w.rp, w.rnorm, w.lists, n, knn_threshold_rank(k), (dg && dg[0] == '1') ? w.diag : nullptr, stream),
+    HIP_TRY(launch_fused(g, w.qp, w.rp, w.rnorm, w.lists, w.pend, n, knn_threshold_rank(k), (dg && dg[0] == '1') ? w.diag : nullptr, stream),
             "fused distance + top-k");
     if (timed) {
         HIP_TRY(hipEventRecord(g_ev1[g_ev_used], stream), "event record");

@@ -31,7 +31,8 @@ struct KnnGeometry {
     int ls;                // row stride of the packed reference image (features, zero pad)
     int RT;                // reference rows per LDS stage
     int nw;                // waves per block of the fused kernel
-    int pcap;              // pending candidates per query (LDS buffer length)
+    int pcap;              // pending candidates per query (buffer length)
+    int gp;                // 1: those buffers live in global memory (workspace), 0: in LDS
     int qpb;               // queries per block
     int nqb;               // query blocks
     int S;                 // reference chunks searched independently
@@ -52,8 +53,8 @@ KnnGeometry knn_geometry(long long n, long long m, int d, int k, int splits);
 hipError_t launch_pack(const float* X, long long n, int d, const KnnGeometry& g, float scale, float* Xp,
                        int ld, float* norms, long long n_pad, unsigned* maxnorm_bits, hipStream_t stream);
 hipError_t launch_fused(const KnnGeometry& g, const float* Qp, const float* Rp, const float* rnorm,
-                        unsigned long long* lists, long long n, int kt, unsigned long long* diag,
-                        hipStream_t stream);
+                        unsigned long long* lists, void* pend_g, long long n, int kt,
+                        unsigned long long* diag, hipStream_t stream);
 hipError_t launch_refine(const float* Q, const float* Qp, const float* Rp, int d, long long n, const KnnGeometry& g,
                          const unsigned long long* lists, int k, int kt, long long col_offset, int merge,
                          const unsigned* maxnorm_bits, int* idx, float* d2, float* dist, double* lb,

@@ -127,7 +127,7 @@ static constexpr unsigned TAU_MAX_BITS = 0x7f000000u;  // 1.7e38: above every re
 __device__ __forceinline__ float score_key(float score, int r) {
     return __uint_as_float((__float_as_uint(score) & KEY_MASK) | (unsigned)r);
 }
-template <int D2, int NW_, int RT_, int PCAP_>
+template <int D2, int NW_, int RT_, int PCAP_, bool GP_>
 struct FusedCfg {
     static constexpr int D2P = (D2 + 3) & ~3;
     static constexpr int ROWF = 2 * D2P;  // feature floats per packed row
@@ -138,9 +138,11 @@ struct FusedCfg {
     static constexpr int NW = NW_;                     // waves per block
     static constexpr int PCAP = PCAP_;                 // pending candidates per query
     static constexpr int NB = 2;                       // LDS stage buffers
+    // pending candidates in global memory (L2) instead of LDS: leaves the LDS to longer stages
+    static constexpr bool GP = GP_;
     static constexpr int QPB = NW * 32;                // queries per block
     static constexpr size_t lds_bytes() {
-        return sizeof(float) * (NB * RT * LS + NB * RT) + sizeof(uint2) * (NW * 32 * PCAP);
+        return sizeof(float) * (NB * RT * LS + NB * RT) + (GP ? 0 : sizeof(uint2) * (NW * 32 * PCAP));
     }
 };
 
@@ -177,14 +179,21 @@ __device__ __forceinline__ float4 lds_read_b128(const float* p) {
 // all 64 lanes cooperating.  Returns the new threshold (key of the kt-th entry).
 // The pending candidates of a query sit in two buffers of HCAP entries, one per lane half
 // of the MFMA layout (c0 and c1 entries in use).
-template <int HCAP>
+template <int HCAP, bool GP>
 __device__ __forceinline__ float flush_query(unsigned c0, unsigned c1, const uint2* pend_q, u64* list_q,
                                              bool inited, int lane, int kt) {
     static_assert(2 * HCAP <= 32, "both buffers are sorted by one 32-lane bitonic network");
     u64 key = LIST_SENTINEL;
     const unsigned h = (unsigned)lane / HCAP, i = (unsigned)lane % HCAP;
     if (h < 2u && i < (h ? c1 : c0)) {
-        uint2 e = pend_q[lane];  // buffer h, entry i
+        uint2 e;  // buffer h, entry i
+        if constexpr (GP) {  // written by this wave a while ago: read from L2, past the L1
+            const u64 raw = __hip_atomic_load(reinterpret_cast<const u64*>(pend_q) + lane, __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_AGENT);
+            e = make_uint2((unsigned)raw, (unsigned)(raw >> 32));
+        } else {
+            e = pend_q[lane];
+        }
         key = ((u64)f2ord(__uint_as_float(e.x)) << 32) | (u64)e.y;
     }
     key = wave_sort<32>(key, lane);  // lanes 0..31 ascending, 32..63 all sentinel
@@ -200,16 +209,17 @@ __device__ __forceinline__ float flush_query(unsigned c0, unsigned c1, const uin
     return ord2f(top);
 }
 
-template <int D2, int NW_, int RT_, int PCAP_, bool DIAG_>
+template <int D2, int NW_, int RT_, int PCAP_, bool GP_, bool DIAG_>
 __global__ __launch_bounds__(NW_ * 64, (NW_ >= 8 ? NW_ / 4 : 2)) void fused_knn_kernel(
     const float* __restrict__ Qp,     // [n_pad][ROWF], already scaled by -2
     const float* __restrict__ Rp,     // [m_pad][LS], zero pad columns
     const float* __restrict__ rnorm,  // [m_pad], 1.7e38 on padding rows
     u64* __restrict__ lists,          // [S][n_pad][64], then the tail region's extra lists
+    uint2* __restrict__ pend_g,       // [shortlists][PCAP] pending candidates (GP_ only)
     long long n, long long n_pad, int nqb, long long chunk_rows, FusedTail tail, int kt, int ablate,
     u64* __restrict__ diag_out /* per wave 8 counters (DIAG_ instantiations only) */) {
     u64* const diag = DIAG_ ? diag_out : nullptr;  // compile-time NULL in the product kernel
-    using C = FusedCfg<D2, NW_, RT_, PCAP_>;
+    using C = FusedCfg<D2, NW_, RT_, PCAP_, GP_>;
     constexpr int D2P = C::D2P, ROWF = C::ROWF, LS = C::LS, RT = C::RT, NW = C::NW;
     constexpr int PCAP = C::PCAP, NSUB = RT / 32, NB = C::NB;
     constexpr int STAGE_BYTES = RT * LS * 4;
@@ -257,7 +267,7 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ >= 8 ? NW_ / 4 : 2)) void fused_knn_
     const int T = (int)(rows_here / RT);
 
     constexpr int HCAP = PCAP / 2;  // each lane appends to a buffer of its own: no atomics
-    uint2* pend_w = pend + wave * 32 * PCAP;
+    uint2* pend_w = GP_ ? pend_g + list_row * PCAP : pend + wave * 32 * PCAP;
     uint2* pend_l = pend_w + (j * 2 + hh) * HCAP;  // this lane's buffer: query j, lane half hh
     unsigned pcnt = 0u;                            // entries in it
     u64* lists_w = lists + list_row * 64;
@@ -309,7 +319,9 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ >= 8 ? NW_ / 4 : 2)) void fused_knn_
     // candidate, or, at the end, no shortlist in memory yet
     auto flush_full = [&](bool only_full, bool force_uninit) __attribute__((always_inline)) {
         const u64 tf0 = diag ? (u64)clock64() : 0;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // the appended entries have reached L2 (stores write through; the merge reads past the L1)
+        if constexpr (GP_) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         bool need = only_full ? (pcnt >= (unsigned)HCAP) : (pcnt > 0u);
         need = need || (force_uninit && !((inited >> j) & 1u) && (q0 + j < n));
         const u64 m64 = __ballot(need);
@@ -319,7 +331,7 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ >= 8 ? NW_ / 4 : 2)) void fused_knn_
             mask &= mask - 1;
             const unsigned c0 = __builtin_amdgcn_readlane(pcnt, q);
             const unsigned c1 = __builtin_amdgcn_readlane(pcnt, q + 32);
-            float nt = flush_query<HCAP>(c0, c1, pend_w + q * PCAP, lists_w + (long long)q * 64,
+            float nt = flush_query<HCAP, GP_>(c0, c1, pend_w + q * PCAP, lists_w + (long long)q * 64,
                                          (inited >> q) & 1u, lane, kt);
             inited |= 1u << q;
             if (j == q) { tau = fminf(nt, tau_max); tau_hi = widen(tau); pcnt = 0u; }
@@ -735,11 +747,12 @@ __global__ __launch_bounds__(EX_NT) void exact_rows_kernel(
 // host-side launchers
 // --------------------------------------------------------------------------------
 static const int kD2Sizes[] = {8, 15, 16, 20, 25, 32, 40, 50, 64};
-// compiled (D2, waves per block, reference rows per LDS stage, pending candidates per query)
+// compiled (D2, waves per block, reference rows per LDS stage, pending candidates per query,
+// pending candidates in global memory)
 #define SCMIAC_FUSED_VARIANTS(X) \
-    X(8, 12, 128, 32) X(15, 12, 128, 32) X(16, 12, 128, 32) X(20, 12, 128, 32) X(25, 12, 128, 32) \
-    X(32, 8, 128, 32) X(40, 8, 64, 32) X(50, 8, 64, 32) X(64, 8, 64, 32) \
-    X(25, 8, 128, 32) X(32, 12, 64, 32) X(32, 12, 128, 24)
+    X(8, 12, 256, 32, 1) X(15, 12, 256, 32, 1) X(16, 12, 256, 32, 1) X(20, 12, 256, 32, 1) X(25, 12, 256, 32, 1) \
+    X(32, 12, 256, 32, 1) X(40, 8, 64, 32, 0) X(50, 8, 64, 32, 0) X(64, 8, 64, 32, 0) \
+    X(25, 12, 128, 32, 0) X(25, 12, 128, 32, 1) X(32, 12, 128, 24, 0)
 
 int knn_pick_d2(int d) {
     int need = (d + 1) / 2;
@@ -748,49 +761,55 @@ int knn_pick_d2(int d) {
     return -1;
 }
 
-template <int D2, int NW, int RT, int PC, bool DIAG>
-static hipError_t launch_fused_t(const float* Qp, const float* Rp, const float* rnorm, u64* lists,
+template <int D2, int NW, int RT, int PC, bool GP, bool DIAG>
+static hipError_t launch_fused_t(const float* Qp, const float* Rp, const float* rnorm, u64* lists, uint2* pend_g,
                                  long long n, long long n_pad, int nqb, int S, long long chunk_rows,
                                  const FusedTail& tail, int kt, u64* diag, hipStream_t stream) {
-    using C = FusedCfg<D2, NW, RT, PC>;
+    using C = FusedCfg<D2, NW, RT, PC, GP>;
     size_t lds = C::lds_bytes();
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_knn_kernel<D2, NW, RT, PC, DIAG>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_knn_kernel<D2, NW, RT, PC, GP, DIAG>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     dim3 grid((unsigned)(tail.block0 + (nqb - tail.qb0) * tail.St)), block(NW * 64);
     int ablate = 0;
     if (const char* v = getenv("SCMIAC_FUSED_ABLATE")) ablate = atoi(v);  // diagnostic builds only
-    hipLaunchKernelGGL((fused_knn_kernel<D2, NW, RT, PC, DIAG>), grid, block, lds, stream, Qp, Rp, rnorm, lists, n,
+    hipLaunchKernelGGL((fused_knn_kernel<D2, NW, RT, PC, GP, DIAG>), grid, block, lds, stream, Qp, Rp, rnorm, lists, pend_g, n,
                        n_pad, nqb, chunk_rows, tail, kt, ablate, diag);
     return hipGetLastError();
 }
 
 // (waves per block, reference rows per LDS stage) of the fused kernel
-static void fused_variant(int D2, int* nw, int* rt, int* pcap) {
-    // 12 waves (3 per SIMD) where the candidate buffers and two stages fit the 160 KiB of LDS
+static void fused_variant(int D2, int* nw, int* rt, int* pcap, int* gp) {
+    // Up to 64 features: 12 waves per block (3 per SIMD), the pending-candidate buffers in
+    // global memory and all of the LDS given to two 256-row stages (fewer barriers, and the
+    // waves' uneven candidate work averages out over a longer stage).  Wider rows: 8 waves,
+    // 64-row stages, buffers in LDS.
     *nw = (D2 <= 32) ? 12 : 8;
-    *rt = (D2 <= 32) ? 128 : 64;
-    *pcap = (D2 == 32) ? 24 : 32;  // 64 features: shorter candidate buffers make room for the wider stages
-    if (const char* v = getenv("SCMIAC_FUSED_VARIANT")) {  // tuning aid: "NWxRTxPCAP", e.g. 8x128x32
-        int a = 0, b = 0, c = 32;
-        if (sscanf(v, "%dx%dx%d", &a, &b, &c) >= 2 && (D2 == 25 || D2 == 32)) { *nw = a; *rt = b; *pcap = c; }
+    *rt = (D2 <= 32) ? 256 : 64;
+    *pcap = 32;
+    *gp = (D2 <= 32) ? 1 : 0;
+    if (const char* v = getenv("SCMIAC_FUSED_VARIANT")) {  // tuning aid: "NWxRTxPCAPxGP", e.g. 12x256x32x1
+        int a = 0, b = 0, c = 32, e = 0;
+        if (sscanf(v, "%dx%dx%dx%d", &a, &b, &c, &e) >= 2 && (D2 == 25 || D2 == 32)) {
+            *nw = a; *rt = b; *pcap = c; *gp = e;
+        }
     }
 }
 
 // blocks of the fused kernel the GPU runs at once (256 one-block CUs when no device answers)
-template <int D2, int NW, int RT, int PC>
+template <int D2, int NW, int RT, int PC, bool GP>
 static int fused_occupancy_t() {
     constexpr bool DIAG = false;
-    using C = FusedCfg<D2, NW, RT, PC>;
+    using C = FusedCfg<D2, NW, RT, PC, GP>;
     int dev = 0, cus = 0, per_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
         (void)hipGetLastError();
         return 256;
     }
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_knn_kernel<D2, NW, RT, PC, DIAG>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_knn_kernel<D2, NW, RT, PC, GP, DIAG>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes());
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_knn_kernel<D2, NW, RT, PC, DIAG>, NW * 64,
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_knn_kernel<D2, NW, RT, PC, GP, DIAG>, NW * 64,
                                                      C::lds_bytes()) != hipSuccess || per_cu <= 0) {
         (void)hipGetLastError();
         per_cu = 1;
@@ -800,12 +819,13 @@ static int fused_occupancy_t() {
 static int fused_concurrent_blocks(const KnnGeometry& g) {
     static int cache[32][2];  // variant -> slots; a handful of variants exist
     static int n_cached = 0;
-    const int tag = ((g.D2 * 100 + g.nw) * 1000 + g.RT) * 100 + g.pcap;
+    const int tag = (((g.D2 * 100 + g.nw) * 1000 + g.RT) * 100 + g.pcap) * 2 + g.gp;
     for (int i = 0; i < n_cached; ++i)
         if (cache[i][0] == tag) return cache[i][1];
     int slots = 256;
-#define SCMIAC_OCC_CASE(V_, NW_, RT_, PC_) \
-    if (g.D2 == V_ && g.nw == NW_ && g.RT == RT_ && g.pcap == PC_) slots = fused_occupancy_t<V_, NW_, RT_, PC_>();
+#define SCMIAC_OCC_CASE(V_, NW_, RT_, PC_, GP_) \
+    if (g.D2 == V_ && g.nw == NW_ && g.RT == RT_ && g.pcap == PC_ && g.gp == GP_) \
+        slots = fused_occupancy_t<V_, NW_, RT_, PC_, (GP_ != 0)>();
     SCMIAC_FUSED_VARIANTS(SCMIAC_OCC_CASE)
 #undef SCMIAC_OCC_CASE
     if (n_cached < 32) { cache[n_cached][0] = tag; cache[n_cached][1] = slots; ++n_cached; }
@@ -819,7 +839,7 @@ KnnGeometry knn_geometry(long long n, long long m, int d, int k, int splits) {
     g.D2P = (g.D2 + 3) & ~3;
     g.rowf = 2 * g.D2P;
     g.ls = g.rowf + (((g.rowf / 4) % 2 == 0) ? 4 : 8);
-    fused_variant(g.D2, &g.nw, &g.RT, &g.pcap);
+    fused_variant(g.D2, &g.nw, &g.RT, &g.pcap, &g.gp);
     g.qpb = g.nw * 32;
     g.n_pad = ((n + g.qpb - 1) / g.qpb) * g.qpb;
     g.nqb = (int)(g.n_pad / g.qpb);
@@ -910,12 +930,13 @@ hipError_t launch_pack(const float* X, long long n, int d, const KnnGeometry& g,
 }
 
 hipError_t launch_fused(const KnnGeometry& g, const float* Qp, const float* Rp, const float* rnorm,
-                        unsigned long long* lists, long long n, int kt, unsigned long long* diag,
-                        hipStream_t stream) {
-#define SCMIAC_FUSED_CASE(V_, NW_, RT_, PC_)                                                       \
-    if (g.D2 == V_ && g.nw == NW_ && g.RT == RT_ && g.pcap == PC_)                                 \
-        return diag ? launch_fused_t<V_, NW_, RT_, PC_, true>(Qp, Rp, rnorm, lists, n, g.n_pad, g.nqb, g.S, g.chunk_rows, g.tail, kt, diag, stream) \
-                    : launch_fused_t<V_, NW_, RT_, PC_, false>(Qp, Rp, rnorm, lists, n, g.n_pad, g.nqb, g.S, g.chunk_rows, g.tail, kt, diag, stream);
+                        unsigned long long* lists, void* pend_g_, long long n, int kt,
+                        unsigned long long* diag, hipStream_t stream) {
+    uint2* pend_g = static_cast<uint2*>(pend_g_);
+#define SCMIAC_FUSED_CASE(V_, NW_, RT_, PC_, GP_)                                                  \
+    if (g.D2 == V_ && g.nw == NW_ && g.RT == RT_ && g.pcap == PC_ && g.gp == GP_)                  \
+        return diag ? launch_fused_t<V_, NW_, RT_, PC_, (GP_ != 0), true>(Qp, Rp, rnorm, lists, pend_g, n, g.n_pad, g.nqb, g.S, g.chunk_rows, g.tail, kt, diag, stream) \
+                    : launch_fused_t<V_, NW_, RT_, PC_, (GP_ != 0), false>(Qp, Rp, rnorm, lists, pend_g, n, g.n_pad, g.nqb, g.S, g.chunk_rows, g.tail, kt, diag, stream);
     SCMIAC_FUSED_VARIANTS(SCMIAC_FUSED_CASE)
     return hipErrorInvalidValue;
 #undef SCMIAC_FUSED_CASE
