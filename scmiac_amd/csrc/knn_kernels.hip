@@ -182,7 +182,7 @@ __device__ __forceinline__ float4 lds_read_b128(const float* p) {
 template <int HCAP, bool GP>
 __device__ __forceinline__ float flush_query(unsigned c0, unsigned c1, const uint2* pend_q, u64* list_q,
                                              bool inited, int lane, int kt) {
-    static_assert(2 * HCAP <= 32, "both buffers are sorted by one 32-lane bitonic network");
+    static_assert(2 * HCAP <= 64, "both buffers are sorted by one bitonic network across the wave");
     u64 key = LIST_SENTINEL;
     const unsigned h = (unsigned)lane / HCAP, i = (unsigned)lane % HCAP;
     if (h < 2u && i < (h ? c1 : c0)) {
@@ -196,7 +196,8 @@ __device__ __forceinline__ float flush_query(unsigned c0, unsigned c1, const uin
         }
         key = ((u64)f2ord(__uint_as_float(e.x)) << 32) | (u64)e.y;
     }
-    key = wave_sort<32>(key, lane);  // lanes 0..31 ascending, 32..63 all sentinel
+    // ascending across the lanes that hold entries (lanes 32..63 are all sentinel when 2 HCAP <= 32)
+    key = (2 * HCAP <= 32) ? wave_sort<32>(key, lane) : wave_sort<64>(key, lane);
     u64 old = LIST_SENTINEL;
     if (inited)  // written earlier by this same wave: read it back from L2, not a stale L1 line
         old = __hip_atomic_load(list_q + (63 - lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -404,19 +405,23 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ >= 8 ? NW_ / 4 : 2)) void fused_knn_
                     if (diag) { ++dg_iters; dg_npush += __popcll(__ballot(p && room)); }
                 }
             }
-            if (__any(skipped != 0u)) {  // merge the full buffers, then the keys left over
-                flush_full(true, false);  // (an emptied buffer takes all 16 keys of a lane)
+            while (__any(skipped != 0u)) {  // merge the full buffers, then the keys left over
+                flush_full(true, false);
+                unsigned still = 0u;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const bool p = ((skipped >> r) & 1u) && key[r] < tau;  // against the tightened threshold
                     if (__any(p)) {
-                        if (p) {
+                        const bool room = pcnt < (unsigned)HCAP;  // a buffer shorter than 16 can fill up again
+                        if (p && room) {
                             pend_l[pcnt] = make_uint2(__float_as_uint(key[r]), ref0 + (unsigned)((r & 3) + 8 * (r >> 2)));
                             ++pcnt;
                         }
-                        if (diag) { ++dg_iters; dg_npush += __popcll(__ballot(p)); }
+                        if (p && !room) still |= 1u << r;
+                        if (diag) { ++dg_iters; dg_npush += __popcll(__ballot(p && room)); }
                     }
                 }
+                skipped = still;
             }
         }
         if (diag) dg_slow += (u64)clock64() - ts0;
@@ -752,7 +757,7 @@ static const int kD2Sizes[] = {8, 15, 16, 20, 25, 32, 40, 50, 64};
 #define SCMIAC_FUSED_VARIANTS(X) \
     X(8, 12, 256, 32, 1) X(15, 12, 256, 32, 1) X(16, 12, 256, 32, 1) X(20, 12, 256, 32, 1) X(25, 12, 256, 32, 1) \
     X(32, 12, 256, 32, 1) X(40, 8, 64, 32, 0) X(50, 8, 64, 32, 0) X(64, 8, 64, 32, 0) \
-    X(25, 12, 128, 32, 0) X(25, 12, 128, 32, 1) X(32, 12, 128, 24, 0)
+    X(25, 12, 128, 32, 0) X(25, 12, 128, 32, 1) X(32, 12, 128, 24, 0) X(25, 12, 256, 16, 1)
 
 int knn_pick_d2(int d) {
     int need = (d + 1) / 2;

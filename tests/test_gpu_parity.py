@@ -340,3 +340,14 @@ def test_ring_search_unit_norm_d64_single_rank(tmp_path):
     np.testing.assert_array_equal(full.cpu().numpy(), idx_o)
     np.testing.assert_array_equal(st.dist2.cpu().numpy(), d2_o)
     assert int(st.n_uncertified.item()) > 0
+
+
+@pytest.mark.parametrize("variant", ["12x256x16x1", "12x128x32x0", "12x128x32x1"])
+def test_knn_kernel_variants_agree_with_oracle(monkeypatch, variant):
+    """Other compiled shapes of the fused kernel (short pending buffers that refill within
+    one subtile, buffers in LDS, 128-row stages) give the same exact result."""
+    monkeypatch.setenv("SCMIAC_FUSED_VARIANT", variant)
+    Q = _mixture(81, 1500, 50)
+    R = _mixture(82, 12000, 50, offset=True)
+    Q[:40] = R[:40]  # queries sitting on references: many small scores early in the stream
+    _check_knn(Q, R, 31)
