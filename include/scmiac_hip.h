@@ -152,10 +152,12 @@ SCMIAC_API int scmiac_anchor_filter(const int64_t *pairs, const int64_t *n_pairs
 
 /*
  * Diagnostic aid (no counterpart in the reference).  When the environment variable
- * SCMIAC_FUSED_DIAG=1 is set, the fused kernel of scmiac_knn_search writes eight
+ * SCMIAC_FUSED_DIAG=1 is set, the fused kernel of scmiac_knn_search writes twelve
  * uint64 counters per wave into the workspace at `offset`:
  *   {wave cycles, cycles in the candidate path, cycles merging shortlists,
- *    candidate-path entries, shortlist merges, candidates taken, 0, 0}.
+ *    candidate-path entries, shortlist merges, candidates taken, register steps,
+ *    cycles up to the duplicate check, cycles of the one-candidate-per-lane store,
+ *    entries that took the general path, 0, 0}.
  */
 SCMIAC_API int scmiac_knn_diag_region(int64_t n, int64_t m, int d, int k, int splits, size_t *offset,
                                       size_t *bytes, int *waves);

@@ -60,7 +60,7 @@ static KnnWs knn_carve(void* ws, long long n, const KnnGeometry& g) {
     off += 256;
     w.diag = reinterpret_cast<unsigned long long*>(p + off);
     w.diag_offset = off;
-    w.diag_bytes = sizeof(unsigned long long) * 8 * (size_t)g.blocks * g.nw;
+    w.diag_bytes = sizeof(unsigned long long) * 12 * (size_t)g.blocks * g.nw;
     off += up256(w.diag_bytes);
     w.total = off;
     return w;

@@ -217,9 +217,10 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ >= 8 ? NW_ / 4 : 2)) void fused_knn_
     const float* __restrict__ rnorm,  // [m_pad], 1.7e38 on padding rows
     u64* __restrict__ lists,          // [S][n_pad][64], then the tail region's extra lists
     uint2* __restrict__ pend_g,       // [shortlists][PCAP] pending candidates (GP_ only)
-    long long n, long long n_pad, int nqb, long long chunk_rows, FusedTail tail, int kt, int ablate,
+    long long n, long long n_pad, int nqb, long long chunk_rows, FusedTail tail, int kt, int ablate_in,
     u64* __restrict__ diag_out /* per wave 8 counters (DIAG_ instantiations only) */) {
-    u64* const diag = DIAG_ ? diag_out : nullptr;  // compile-time NULL in the product kernel
+    u64* const diag = DIAG_ ? diag_out : nullptr;  // compile-time NULL in the product kernel (may be NULL in the other too)
+    const int ablate = DIAG_ ? ablate_in : 0;      // ablations exist in the diagnostic instantiations only
     using C = FusedCfg<D2, NW_, RT_, PCAP_, GP_>;
     constexpr int D2P = C::D2P, ROWF = C::ROWF, LS = C::LS, RT = C::RT, NW = C::NW;
     constexpr int PCAP = C::PCAP, NSUB = RT / 32, NB = C::NB;
@@ -314,6 +315,7 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ >= 8 ? NW_ / 4 : 2)) void fused_knn_
     } while (0)
 
     u64 dg_slow = 0, dg_flush = 0, dg_nslow = 0, dg_nflush = 0, dg_npush = 0, dg_iters = 0;
+    u64 dg_seg1 = 0, dg_seg2 = 0, dg_ngen = 0;
     const u64 dg_t0 = diag ? (u64)clock64() : 0;
 
     // merge every query of this wave that has a full buffer (only_full) or any pending
@@ -374,23 +376,28 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ >= 8 ? NW_ / 4 : 2)) void fused_knn_
             twice |= seen & m;
             seen |= m;
         }
+        const u64 ts1 = diag ? (u64)clock64() : 0;
+        if (diag) dg_seg1 += ts1 - ts0;  // keys, smallest key, duplicate check
         if (ablate & 16) {  // diagnostic: price of the arithmetic above without any store
             asm volatile("" ::"v"(kmin), "s"(twice));
             return;
         }
         if (twice == 0ull) {
             // the usual case: at most one candidate per lane, and it is the lane's smallest key
+            // (key register r holds subtile row (r & 3) + 8 (r >> 2) = r + (r & 12))
+            const unsigned kb = __float_as_uint(kmin);
+            const uint2 entry = make_uint2(kb, ref0 + (kb & 15u) + (kb & 12u));
             const bool p = kmin < tau;
-            if (__any(p && pcnt >= (unsigned)HCAP)) flush_full(true, false);
-            if (p && kmin < tau) {
-                const unsigned kb = __float_as_uint(kmin);
-                // key register r holds subtile row (r & 3) + 8 (r >> 2) = r + (r & 12)
-                if (!(ablate & 32))  // diagnostic: everything but the store itself
-                    pend_l[pcnt] = make_uint2(kb, ref0 + (kb & 15u) + (kb & 12u));
+            if (__any(p && pcnt >= (unsigned)HCAP)) {  // rare: make room first, then test again
+                flush_full(true, false);
+                if (p && kmin < tau) { pend_l[pcnt] = entry; ++pcnt; }
+            } else if (p) {
+                pend_l[pcnt] = entry;
                 ++pcnt;
             }
-            if (diag) { ++dg_iters; dg_npush += __popcll(__ballot(p)); }
+            if (diag) { ++dg_iters; dg_npush += __popcll(__ballot(p)); dg_seg2 += (u64)clock64() - ts1; }
         } else {
+            if (diag) ++dg_ngen;
             unsigned skipped = 0u;  // bit r: key[r] passed but this lane's buffer was full
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -497,9 +504,10 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ >= 8 ? NW_ / 4 : 2)) void fused_knn_
     }
     flush_full(false, true);
     if (diag && lane == 0) {
-        u64* o = diag + ((long long)blockIdx.x * NW + wave) * 8;
+        u64* o = diag + ((long long)blockIdx.x * NW + wave) * 12;
         o[0] = (u64)clock64() - dg_t0; o[1] = dg_slow; o[2] = dg_flush; o[3] = dg_nslow;
-        o[4] = dg_nflush; o[5] = dg_npush; o[6] = dg_iters; o[7] = 0;
+        o[4] = dg_nflush; o[5] = dg_npush; o[6] = dg_iters; o[7] = dg_seg1;
+        o[8] = dg_seg2; o[9] = dg_ngen; o[10] = 0; o[11] = 0;
     }
 #undef SCMIAC_STAGE
 #undef SCMIAC_LOAD_FRAGS
@@ -769,15 +777,13 @@ int knn_pick_d2(int d) {
 template <int D2, int NW, int RT, int PC, bool GP, bool DIAG>
 static hipError_t launch_fused_t(const float* Qp, const float* Rp, const float* rnorm, u64* lists, uint2* pend_g,
                                  long long n, long long n_pad, int nqb, int S, long long chunk_rows,
-                                 const FusedTail& tail, int kt, u64* diag, hipStream_t stream) {
+                                 const FusedTail& tail, int kt, int ablate, u64* diag, hipStream_t stream) {
     using C = FusedCfg<D2, NW, RT, PC, GP>;
     size_t lds = C::lds_bytes();
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_knn_kernel<D2, NW, RT, PC, GP, DIAG>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     dim3 grid((unsigned)(tail.block0 + (nqb - tail.qb0) * tail.St)), block(NW * 64);
-    int ablate = 0;
-    if (const char* v = getenv("SCMIAC_FUSED_ABLATE")) ablate = atoi(v);  // diagnostic builds only
     hipLaunchKernelGGL((fused_knn_kernel<D2, NW, RT, PC, GP, DIAG>), grid, block, lds, stream, Qp, Rp, rnorm, lists, pend_g, n,
                        n_pad, nqb, chunk_rows, tail, kt, ablate, diag);
     return hipGetLastError();
@@ -938,10 +944,15 @@ hipError_t launch_fused(const KnnGeometry& g, const float* Qp, const float* Rp, 
                         unsigned long long* lists, void* pend_g_, long long n, int kt,
                         unsigned long long* diag, hipStream_t stream) {
     uint2* pend_g = static_cast<uint2*>(pend_g_);
+    // counters (diag) and ablations (SCMIAC_FUSED_ABLATE bits: 1 no selection, 2 no staging,
+    // 4 no barrier, 8 empty candidate path, 16 candidate arithmetic only) live in a separate
+    // instantiation of the kernel; the product kernel carries neither
+    int ablate = 0;
+    if (const char* v = getenv("SCMIAC_FUSED_ABLATE")) ablate = atoi(v);
 #define SCMIAC_FUSED_CASE(V_, NW_, RT_, PC_, GP_)                                                  \
     if (g.D2 == V_ && g.nw == NW_ && g.RT == RT_ && g.pcap == PC_ && g.gp == GP_)                  \
-        return diag ? launch_fused_t<V_, NW_, RT_, PC_, (GP_ != 0), true>(Qp, Rp, rnorm, lists, pend_g, n, g.n_pad, g.nqb, g.S, g.chunk_rows, g.tail, kt, diag, stream) \
-                    : launch_fused_t<V_, NW_, RT_, PC_, (GP_ != 0), false>(Qp, Rp, rnorm, lists, pend_g, n, g.n_pad, g.nqb, g.S, g.chunk_rows, g.tail, kt, diag, stream);
+        return (diag || ablate) ? launch_fused_t<V_, NW_, RT_, PC_, (GP_ != 0), true>(Qp, Rp, rnorm, lists, pend_g, n, g.n_pad, g.nqb, g.S, g.chunk_rows, g.tail, kt, ablate, diag, stream) \
+                    : launch_fused_t<V_, NW_, RT_, PC_, (GP_ != 0), false>(Qp, Rp, rnorm, lists, pend_g, n, g.n_pad, g.nqb, g.S, g.chunk_rows, g.tail, kt, 0, diag, stream);
     SCMIAC_FUSED_VARIANTS(SCMIAC_FUSED_CASE)
     return hipErrorInvalidValue;
 #undef SCMIAC_FUSED_CASE

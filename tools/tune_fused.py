@@ -25,7 +25,7 @@ def main():
     ap.add_argument("--k", type=int, default=30)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--splits", type=int, default=0)
-    ap.add_argument("--variants", nargs="+", default=["12x128x32"])
+    ap.add_argument("--variants", nargs="+", default=["default"], help='"WAVESxSTAGE_ROWSxPENDINGxGLOBAL" or "default"')
     ap.add_argument("--workload", default="c3", help="bench.py workload the latents are drawn from")
     args = ap.parse_args()
     U, V, _, _, d = bench.make_latents(args.workload, args.n, args.m)
@@ -34,7 +34,10 @@ def main():
     ref_idx = None
     for rnd in range(args.rounds + 1):
         for v in args.variants:
-            os.environ["SCMIAC_FUSED_VARIANT"] = v
+            if v == "default":
+                os.environ.pop("SCMIAC_FUSED_VARIANT", None)
+            else:
+                os.environ["SCMIAC_FUSED_VARIANT"] = v
             _hip.set_timing(True)
             # ablated kernels leave poor shortlists: skip the direct-evaluation pass they would trigger
             ablated = os.environ.get("SCMIAC_FUSED_ABLATE", "0") != "0"
@@ -56,7 +59,9 @@ def main():
               f"candidate path {100 * dg[:, 1].sum() / tot.sum():.2f} %  of which merges {100 * dg[:, 2].sum() / tot.sum():.2f} %  "
               f"entries/wave {dg[:, 3].mean():.0f}  merges/wave {dg[:, 4].mean():.0f}  candidates/wave {dg[:, 5].mean():.0f}  "
               f"cycles/entry {dg[:, 1].sum() / max(dg[:, 3].sum(), 1):.0f}  cycles/merge {dg[:, 2].sum() / max(dg[:, 4].sum(), 1):.0f}  "
-              f"iters/wave {dg[:, 6].mean():.0f}  store-segment cycles/iter {dg[:, 7].sum() / max(dg[:, 6].sum(), 1):.0f}")
+              f"register steps/wave {dg[:, 6].mean():.0f}  cycles to duplicate check/entry {dg[:, 7].sum() / max(dg[:, 3].sum(), 1):.0f}  "
+              f"one-candidate store cycles/entry {dg[:, 8].sum() / max((dg[:, 3] - dg[:, 9]).sum(), 1):.0f}  "
+              f"general-path entries/wave {dg[:, 9].mean():.0f}")
     flops = 2.0 * args.n * args.m * d
     for v in args.variants:
         ms = np.array(res[v])
