@@ -127,6 +127,28 @@ static constexpr unsigned TAU_MAX_BITS = 0x7f000000u;  // 1.7e38: above every re
 __device__ __forceinline__ float score_key(float score, int r) {
     return __uint_as_float((__float_as_uint(score) & KEY_MASK) | (unsigned)r);
 }
+// min of three / two floats as single instructions.  fminf() would first canonicalise
+// its operands (two extra VALU instructions per subtile, each worth 4 cycles of MFMA issue);
+// the scores are never signalling NaNs.
+__device__ __forceinline__ float min3_raw(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// The same, for operands that an MFMA may have written only just before: the compiler
+// does not see through inline assembly, so the wait states the ISA asks for between a
+// 16-pass MFMA's write and a VALU read of the same registers (18) are spelled out here.
+__device__ __forceinline__ float min3_after_mfma(float a, float b, float c) {
+    float r;
+    asm("s_nop 15\n\ts_nop 1\n\tv_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float min2_raw(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 template <int D2, int NW_, int RT_, int PCAP_, bool GP_>
 struct FusedCfg {
     static constexpr int D2P = (D2 + 3) & ~3;
@@ -467,10 +489,10 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ >= 8 ? NW_ / 4 : 2)) void fused_knn_
         _Pragma("unroll") for (int s = 0; s < HEAD; ++s)                                            \
             accs[CUR_] = __builtin_amdgcn_mfma_f32_32x32x2f32(rfr[CUR_][s], qf[s], accs[CUR_], 0, 0, 0); \
         if ((SUB_) + 1 < NSUB) SCMIAC_LOAD_FRAGS(rfr[PRV_], tb, (SUB_) + 1);                        \
-        float mn_ = fminf(fminf(accs[PRV_][0], accs[PRV_][1]), accs[PRV_][2]);                      \
+        float mn_ = min3_after_mfma(accs[PRV_][0], accs[PRV_][1], accs[PRV_][2]);                   \
         _Pragma("unroll") for (int r = 3; r < 15; r += 2)                                           \
-            mn_ = fminf(fminf(mn_, accs[PRV_][r]), accs[PRV_][r + 1]);                              \
-        mn_ = fminf(mn_, accs[PRV_][15]);                                                           \
+            mn_ = min3_raw(mn_, accs[PRV_][r], accs[PRV_][r + 1]);                                  \
+        mn_ = min2_raw(mn_, accs[PRV_][15]);                                                        \
         _Pragma("unroll") for (int s = HEAD; s < D2; ++s)                                           \
             accs[CUR_] = __builtin_amdgcn_mfma_f32_32x32x2f32(rfr[CUR_][s], qf[s], accs[CUR_], 0, 0, 0); \
         ref0s[CUR_] = (unsigned)(r_begin + (long long)t * RT + (SUB_) * 32 + 4 * hh);               \
