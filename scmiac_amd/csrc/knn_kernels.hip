@@ -371,7 +371,8 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ >= 8 ? NW_ / 4 : 2)) void fused_knn_
     // step that depends on the one before costs a wave hundreds of cycles while its SIMD
     // partners keep the MFMA pipe busy, so the path is kept shallow: no cross-lane
     // traffic, no atomics, no search for minima.
-    auto select_slow = [&](const f32x16& acc, unsigned ref0) __attribute__((always_inline)) {
+    auto select_slow = [&](const f32x16& acc, unsigned ref0_wave) __attribute__((always_inline)) {
+        const unsigned ref0 = ref0_wave + 4u * (unsigned)hh;  // first reference row of this lane half
         const u64 ts0 = diag ? (u64)clock64() : 0;
         if (diag) ++dg_nslow;
         if (ablate & 8) {  // diagnostic: price of reaching this path and returning
@@ -489,13 +490,17 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ >= 8 ? NW_ / 4 : 2)) void fused_knn_
         _Pragma("unroll") for (int s = 0; s < HEAD; ++s)                                            \
             accs[CUR_] = __builtin_amdgcn_mfma_f32_32x32x2f32(rfr[CUR_][s], qf[s], accs[CUR_], 0, 0, 0); \
         if ((SUB_) + 1 < NSUB) SCMIAC_LOAD_FRAGS(rfr[PRV_], tb, (SUB_) + 1);                        \
-        float mn_ = min3_after_mfma(accs[PRV_][0], accs[PRV_][1], accs[PRV_][2]);                   \
-        _Pragma("unroll") for (int r = 3; r < 15; r += 2)                                           \
-            mn_ = min3_raw(mn_, accs[PRV_][r], accs[PRV_][r + 1]);                                  \
-        mn_ = min2_raw(mn_, accs[PRV_][15]);                                                        \
+        /* smallest of the 16 scores as a depth-3 tree: a wave waits its turn for every */          \
+        /* instruction that depends on the one before, so depth costs more than count   */          \
+        const float m0_ = min3_after_mfma(accs[PRV_][0], accs[PRV_][1], accs[PRV_][2]);             \
+        const float m1_ = min3_raw(accs[PRV_][3], accs[PRV_][4], accs[PRV_][5]);                    \
+        const float m2_ = min3_raw(accs[PRV_][6], accs[PRV_][7], accs[PRV_][8]);                    \
+        const float m3_ = min3_raw(accs[PRV_][9], accs[PRV_][10], accs[PRV_][11]);                  \
+        const float m4_ = min3_raw(accs[PRV_][12], accs[PRV_][13], accs[PRV_][14]);                 \
+        const float mn_ = min2_raw(min3_raw(m0_, m1_, m2_), min3_raw(m3_, m4_, accs[PRV_][15]));    \
         _Pragma("unroll") for (int s = HEAD; s < D2; ++s)                                           \
             accs[CUR_] = __builtin_amdgcn_mfma_f32_32x32x2f32(rfr[CUR_][s], qf[s], accs[CUR_], 0, 0, 0); \
-        ref0s[CUR_] = (unsigned)(r_begin + (long long)t * RT + (SUB_) * 32 + 4 * hh);               \
+        ref0s[CUR_] = (unsigned)(r_begin + (long long)t * RT + (SUB_) * 32); /* wave-uniform */     \
         if (__any(mn_ < tau_hi)) select_slow(accs[PRV_], ref0s[PRV_]);                              \
     } while (0)
 
