@@ -989,7 +989,9 @@ hipError_t launch_refine(const float* Q, const float* Qp, const float* Rp, int d
                          const unsigned long long* lists, int k, int kt, long long col_offset, int merge,
                          const unsigned* maxnorm_bits, int* idx, float* d2, float* dist, double* lb,
                          int* fail_rows, int* n_fail, hipStream_t stream) {
-    // rounding-error model of the fused score (see the derivation in DESIGN.md):
+    // rounding-error model of the fused score s against T = |q|^2 + |r|^2 - 2 q.r (exact),
+    // with gamma_n = n u / (1 - n u), u = 2^-24: the MFMA chain (2*D2 products) and the norm
+    // chain (d terms) are each a float32 inner product, so
     //   |s + |q|^2 - T| <= G (|r| + |q|)^2 <= 2 G (|r|^2 + |q|^2),  G = gamma_{d + 2*D2 + 1}
     //   D >= T (1 - gamma_{d+2})
     // both taken with a factor-two margin.

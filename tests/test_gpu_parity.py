@@ -351,3 +351,16 @@ def test_knn_kernel_variants_agree_with_oracle(monkeypatch, variant):
     R = _mixture(82, 12000, 50, offset=True)
     Q[:40] = R[:40]  # queries sitting on references: many small scores early in the stream
     _check_knn(Q, R, 31)
+
+
+def test_knn_empty_query_and_empty_reference():
+    """No query rows: nothing to do.  No reference rows: every slot is padding (-1 / inf),
+    as for k > m."""
+    R = _mixture(91, 50, 20)
+    st = _hip.knn_search(torch.zeros((0, 20), device="cuda"), _dev(R), 5)
+    assert st.idx.shape == (0, 5) and int(st.n_uncertified.item()) == 0
+    Q = _mixture(92, 70, 20)
+    st = _hip.knn_search(_dev(Q), torch.zeros((0, 20), device="cuda"), 5)
+    torch.cuda.synchronize()
+    assert bool((st.idx == -1).all()) and bool(torch.isinf(st.dist2).all())
+    assert int(st.n_uncertified.item()) == 0
