@@ -89,7 +89,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    # SCMIAC_BENCH_FORCE_DIST=1 runs the multi-rank code path (process group, gather) with a
+    # single rank: a rehearsal of the N > 1 launch on a one-GPU box
+    distributed = world > 1 or os.environ.get("SCMIAC_BENCH_FORCE_DIST") == "1"
     if distributed and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
     torch.cuda.set_device(local_rank)

@@ -35,8 +35,6 @@ def shard_bounds(n, world, rank):
 def gather_rows(local, n, group=None):
     """All-gather of per-shard row blocks laid out by :func:`shard_bounds` -> ``[n, ...]``."""
     world = dist.get_world_size(group)
-    if world == 1:
-        return local
     per = (n + world - 1) // world
     if local.shape[0] < per:  # short or empty last shards: every rank contributes equally
         pad = local.new_full((per - local.shape[0],) + tuple(local.shape[1:]), -1)
