@@ -6,8 +6,9 @@
 //   pack_rows      Q, R  -> MFMA-friendly padded copies, |r|^2, max |r|^2
 //   fused_knn      for every query the 64 references with the smallest
 //                  s(q,r) = |r|^2 - 2 q.r   (fp32 MFMA 32x32x2, refs staged in LDS,
-//                  running threshold in a register, candidate buffers in LDS,
-//                  wave-wide bitonic merges) -- the N x M matrix never leaves the CU
+//                  running threshold in a register, per-lane candidate buffers in
+//                  global memory (L2) or LDS, wave-wide bitonic merges) -- the N x M
+//                  matrix never leaves the CU
 //   refine         exact D(q,r) for the 64*S shortlisted references, (D, index) sort,
 //                  top-k, and a rounding-error certificate that nothing outside the
 //                  shortlist can belong to the top-k
