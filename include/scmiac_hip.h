@@ -80,8 +80,8 @@ SCMIAC_API int scmiac_knn_workspace_size(int64_t n, int64_t m, int d, int k, int
  *                 scmiac_knn_exact_rows for each block afterwards).
  *   1 <= k <= SCMIAC_KNN_MAX_K, 1 <= d <= SCMIAC_KNN_MAX_D, n, m < 2^31.
  *   Inputs must be finite with squared row norms below 1e37 (latent embeddings are
- *   many orders of magnitude inside that); rows containing NaN end up in
- *   uncertified_rows and are ordered by the direct-evaluation pass.
+ *   many orders of magnitude inside that).  Rows containing NaN or infinities do not
+ *   fault or hang the search, but their results are unspecified.
  */
 SCMIAC_API int scmiac_knn_search(const float *q, int64_t n, const float *r, int64_t m, int d, int k,
                       int64_t col_offset, int merge, int splits, int32_t *idx, float *dist2,
