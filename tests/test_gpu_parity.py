@@ -364,3 +364,23 @@ def test_knn_empty_query_and_empty_reference():
     torch.cuda.synchronize()
     assert bool((st.idx == -1).all()) and bool(torch.isinf(st.dist2).all())
     assert int(st.n_uncertified.item()) == 0
+
+
+def test_knn_non_finite_rows_do_not_disturb_the_rest():
+    """NaN / infinite rows are outside the contract, but they must neither hang the search
+    nor change the neighbours of finite query rows among finite reference rows."""
+    Q = _mixture(93, 300, 30)
+    R = _mixture(94, 2000, 30, offset=True)
+    bad = [17, 900]
+    Rb = R.copy()
+    Rb[17] = np.nan
+    Rb[900, 3] = np.inf
+    Qb = Q.copy()
+    Qb[5] = np.nan
+    st = _hip.knn_search(_dev(Qb), _dev(Rb), 10)
+    torch.cuda.synchronize()
+    keep = np.setdiff1d(np.arange(2000), bad)
+    idx_o, d2_o = oracle.knn_dist2(Q, R[keep], 10)
+    rows = np.setdiff1d(np.arange(300), [5])
+    np.testing.assert_array_equal(st.idx.cpu().numpy()[rows], keep[idx_o][rows])
+    np.testing.assert_array_equal(st.dist2.cpu().numpy()[rows], d2_o[rows])
