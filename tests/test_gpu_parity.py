@@ -334,6 +334,12 @@ def test_ring_search_unit_norm_d64_single_rank(tmp_path):
         st = sharded.knn_ring(_dev(Q), _dev(R), 30)
         torch.cuda.synchronize()
         full = sharded.gather_rows(st.idx, len(Q))
+        # replicated mode: the four tables through the sharded driver == the single-process ones
+        U, V = _dev(_mixture(73, 700, 64, unit=True)), _dev(_mixture(74, 900, 64, unit=True))
+        a = sharded.find_neighbor_sharded(U, V, 30)
+        b = anchor_search.find_neighbor_device(U, V, 30)
+        for x, y in zip((a.G11, a.G12, a.G21, a.G22), (b.G11, b.G12, b.G21, b.G22)):
+            assert torch.equal(x, y)
     finally:
         dist.destroy_process_group()
     idx_o, d2_o = oracle.knn_dist2(Q, R, 30)
