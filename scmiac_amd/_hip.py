@@ -7,12 +7,13 @@ if the library is missing or no MI355X is visible, the calls raise.
 from __future__ import annotations
 
 import ctypes
+import os
 from pathlib import Path
 
 import torch
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "csrc" / "libscmiac_hip.so"
+LIB_PATH = Path(os.environ.get("SCMIAC_HIP_LIB", _HERE / "csrc" / "libscmiac_hip.so"))  # override: experiment builds
 
 KNN_MAX_K = 64
 KNN_MAX_D = 128

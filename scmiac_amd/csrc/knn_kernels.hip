@@ -243,7 +243,10 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ >= 8 ? NW_ / 4 : 2)) void fused_knn_
     long long n, long long n_pad, int nqb, long long chunk_rows, FusedTail tail, int kt, int ablate_in,
     u64* __restrict__ diag_out /* per wave 8 counters (DIAG_ instantiations only) */) {
     u64* const diag = DIAG_ ? diag_out : nullptr;  // compile-time NULL in the product kernel (may be NULL in the other too)
-    const int ablate = DIAG_ ? ablate_in : 0;      // ablations exist in the diagnostic instantiations only
+#ifndef SCMIAC_ABL
+#define SCMIAC_ABL 0  // experiment builds (-DSCMIAC_ABL=bits) bake an ablation into the product kernel
+#endif
+    const int ablate = DIAG_ ? ablate_in : SCMIAC_ABL;  // otherwise ablations exist in the diagnostic instantiations only
     using C = FusedCfg<D2, NW_, RT_, PCAP_, GP_>;
     constexpr int D2P = C::D2P, ROWF = C::ROWF, LS = C::LS, RT = C::RT, NW = C::NW;
     constexpr int PCAP = C::PCAP, NSUB = RT / 32, NB = C::NB;
@@ -480,17 +483,25 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ >= 8 ? NW_ / 4 : 2)) void fused_knn_
             (DST_)[4 * c + 2] = v.z; (DST_)[4 * c + 3] = v.w;                                       \
         }                                                                                           \
     } while (0)
-// one subtile: CUR_/PRV_ are the compile-time indices of the two register sets
+// accumulator set SET_ <- |r|^2 of subtile SUB_ (the MFMA chain then adds -2 q.r on top)
+#define SCMIAC_LOAD_NORMS(SET_, SUB_)                                                               \
+    do {                                                                                            \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                             \
+            float4 nv = lds_read_b128(nb + (SUB_) * 32 + 8 * g + 4 * hh);                           \
+            accs[SET_][4 * g + 0] = nv.x; accs[SET_][4 * g + 1] = nv.y;                             \
+            accs[SET_][4 * g + 2] = nv.z; accs[SET_][4 * g + 3] = nv.w;                             \
+        }                                                                                           \
+    } while (0)
+// One subtile: CUR_/PRV_ are the compile-time indices of the two register sets.  On entry
+// accs[CUR_] holds the subtile's |r|^2 and rfr[CUR_] its fragments, both fetched while the
+// previous subtile's chain ran, so the first MFMA follows the previous chain's last one
+// without an LDS wait (the three waves of a SIMD run in step and would all be waiting at
+// the same time).  The previous subtile's scores are tested after the first MFMAs; once
+// they are dealt with, their registers take the next subtile's |r|^2 and fragments.
 #define SCMIAC_SUBTILE(CUR_, PRV_, SUB_)                                                            \
     do {                                                                                            \
-        _Pragma("unroll") for (int g = 0; g < 4; ++g) { /* accumulator starts at |r|^2 */           \
-            float4 nv = lds_read_b128(nb + (SUB_) * 32 + 8 * g + 4 * hh);                           \
-            accs[CUR_][4 * g + 0] = nv.x; accs[CUR_][4 * g + 1] = nv.y;                             \
-            accs[CUR_][4 * g + 2] = nv.z; accs[CUR_][4 * g + 3] = nv.w;                             \
-        }                                                                                           \
         _Pragma("unroll") for (int s = 0; s < HEAD; ++s)                                            \
             accs[CUR_] = __builtin_amdgcn_mfma_f32_32x32x2f32(rfr[CUR_][s], qf[s], accs[CUR_], 0, 0, 0); \
-        if ((SUB_) + 1 < NSUB) SCMIAC_LOAD_FRAGS(rfr[PRV_], tb, (SUB_) + 1);                        \
         /* smallest of the 16 scores as a depth-3 tree: a wave waits its turn for every */          \
         /* instruction that depends on the one before, so depth costs more than count   */          \
         const float m0_ = min3_after_mfma(accs[PRV_][0], accs[PRV_][1], accs[PRV_][2]);             \
@@ -499,10 +510,14 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ >= 8 ? NW_ / 4 : 2)) void fused_knn_
         const float m3_ = min3_raw(accs[PRV_][9], accs[PRV_][10], accs[PRV_][11]);                  \
         const float m4_ = min3_raw(accs[PRV_][12], accs[PRV_][13], accs[PRV_][14]);                 \
         const float mn_ = min2_raw(min3_raw(m0_, m1_, m2_), min3_raw(m3_, m4_, accs[PRV_][15]));    \
+        if (__any(mn_ < tau_hi)) select_slow(accs[PRV_], ref0s[PRV_]);                              \
+        if ((SUB_) + 1 < NSUB) {                                                                    \
+            SCMIAC_LOAD_NORMS(PRV_, (SUB_) + 1);                                                    \
+            SCMIAC_LOAD_FRAGS(rfr[PRV_], tb, (SUB_) + 1);                                           \
+        }                                                                                           \
         _Pragma("unroll") for (int s = HEAD; s < D2; ++s)                                           \
             accs[CUR_] = __builtin_amdgcn_mfma_f32_32x32x2f32(rfr[CUR_][s], qf[s], accs[CUR_], 0, 0, 0); \
         ref0s[CUR_] = (unsigned)(r_begin + (long long)t * RT + (SUB_) * 32); /* wave-uniform */     \
-        if (__any(mn_ < tau_hi)) select_slow(accs[PRV_], ref0s[PRV_]);                              \
     } while (0)
 
     {   // Two stage buffers, one block barrier per stage.
@@ -513,7 +528,9 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ >= 8 ? NW_ / 4 : 2)) void fused_knn_
             if (do_stage && t + 1 < T) SCMIAC_STAGE(t + 1, (t + 1) & 1);
             const float* tb = tile + (do_stage ? (t & 1) : 0) * RT * LS;
             const float* nb = tnorm + (do_stage ? (t & 1) : 0) * RT;
-            // fragments of the stage's first subtile (the stage only became readable at the barrier)
+            // |r|^2 and fragments of the stage's first subtile (the stage only became readable at
+            // the barrier; set 0 was tested during the previous stage's last subtile)
+            SCMIAC_LOAD_NORMS(0, 0);
             SCMIAC_LOAD_FRAGS(rfr[0], tb, 0);
 #pragma unroll
             for (int sp = 0; sp < NSUB; sp += 2) {
@@ -539,6 +556,7 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ >= 8 ? NW_ / 4 : 2)) void fused_knn_
     }
 #undef SCMIAC_STAGE
 #undef SCMIAC_LOAD_FRAGS
+#undef SCMIAC_LOAD_NORMS
 #undef SCMIAC_SUBTILE
 }
 
