@@ -136,6 +136,14 @@ __device__ __forceinline__ float min3_raw(float a, float b, float c) {
     asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+// The same, ordered after the statement that produced `after` (an operand the instruction
+// does not use): the compiler is free to move independent asm statements past each other,
+// and a read of MFMA results must not overtake the one that carries the wait states.
+__device__ __forceinline__ float min3_raw_after(float a, float b, float c, float after) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c), "v"(after));
+    return r;
+}
 // The same, for operands that an MFMA may have written only just before: the compiler
 // does not see through inline assembly, so the wait states the ISA asks for between a
 // 16-pass MFMA's write and a VALU read of the same registers (18) are spelled out here.
@@ -505,10 +513,10 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ >= 8 ? NW_ / 4 : 2)) void fused_knn_
         /* smallest of the 16 scores as a depth-3 tree: a wave waits its turn for every */          \
         /* instruction that depends on the one before, so depth costs more than count   */          \
         const float m0_ = min3_after_mfma(accs[PRV_][0], accs[PRV_][1], accs[PRV_][2]);             \
-        const float m1_ = min3_raw(accs[PRV_][3], accs[PRV_][4], accs[PRV_][5]);                    \
-        const float m2_ = min3_raw(accs[PRV_][6], accs[PRV_][7], accs[PRV_][8]);                    \
-        const float m3_ = min3_raw(accs[PRV_][9], accs[PRV_][10], accs[PRV_][11]);                  \
-        const float m4_ = min3_raw(accs[PRV_][12], accs[PRV_][13], accs[PRV_][14]);                 \
+        const float m1_ = min3_raw_after(accs[PRV_][3], accs[PRV_][4], accs[PRV_][5], m0_);         \
+        const float m2_ = min3_raw_after(accs[PRV_][6], accs[PRV_][7], accs[PRV_][8], m0_);         \
+        const float m3_ = min3_raw_after(accs[PRV_][9], accs[PRV_][10], accs[PRV_][11], m0_);       \
+        const float m4_ = min3_raw_after(accs[PRV_][12], accs[PRV_][13], accs[PRV_][14], m0_);      \
         const float mn_ = min2_raw(min3_raw(m0_, m1_, m2_), min3_raw(m3_, m4_, accs[PRV_][15]));    \
         if (__any(mn_ < tau_hi)) select_slow(accs[PRV_], ref0s[PRV_]);                              \
         if ((SUB_) + 1 < NSUB) {                                                                    \

@@ -316,6 +316,13 @@ def test_large_search_sampled_against_oracle():
     idx_o, d2_o = oracle.knn_dist2(Q[rows].cpu().numpy(), R.cpu().numpy(), 30)
     np.testing.assert_array_equal(st.idx[rows].cpu().numpy(), idx_o)
     np.testing.assert_array_equal(st.dist2[rows].cpu().numpy(), d2_o)
+    # the same search again gives the same table: a read of matrix-core results that
+    # overtook its wait states would show up as run-to-run differences long before it
+    # showed up in a 2 000-row sample
+    first = st.idx.clone()
+    for _ in range(2):
+        again = _hip.knn_search(Q, R, 30)
+        assert torch.equal(again.idx, first)
 
 
 def test_ring_search_unit_norm_d64_single_rank(tmp_path):
