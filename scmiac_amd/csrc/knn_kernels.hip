@@ -403,13 +403,19 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ >= 8 ? NW_ / 4 : 2)) void fused_knn_
         const float a2 = fminf(fminf(key[6], key[7]), key[8]), a3 = fminf(fminf(key[9], key[10]), key[11]);
         const float a4 = fminf(fminf(key[12], key[13]), key[14]);
         const float kmin = fminf(fminf(fminf(a0, a1), a2), fminf(fminf(a3, a4), key[15]));
-        // does any lane have two keys below its threshold?  (scalar bookkeeping on the masks)
+        // does any lane have two keys below its threshold?  Scalar bookkeeping on the compare
+        // masks, four registers at a time and then across the four groups: a single chain
+        // over all sixteen would be 32 scalar instructions each waiting for the one before.
         u64 seen = 0ull, twice = 0ull;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const u64 m = __ballot(key[r] < tau);
-            twice |= seen & m;
-            seen |= m;
+        for (int g = 0; g < 4; ++g) {
+            const u64 ma = __ballot(key[4 * g + 0] < tau), mb = __ballot(key[4 * g + 1] < tau);
+            const u64 mc = __ballot(key[4 * g + 2] < tau), md = __ballot(key[4 * g + 3] < tau);
+            const u64 sab = ma | mb, scd = mc | md;
+            const u64 sg = sab | scd;
+            const u64 tg = (ma & mb) | (mc & md) | (sab & scd);
+            twice |= tg | (seen & sg);
+            seen |= sg;
         }
         const u64 ts1 = diag ? (u64)clock64() : 0;
         if (diag) dg_seg1 += ts1 - ts0;  // keys, smallest key, duplicate check
