@@ -80,33 +80,45 @@ __device__ __forceinline__ u64 wave_merge(u64 key, int lane) {
 // one contiguous image of an LDS stage).  norms[row] = fmaf chain of x_i^2 (feature
 // order), 1.7e38 on the padding rows (they can then never be candidates).
 // --------------------------------------------------------------------------------
-__global__ void pack_rows_kernel(const float* __restrict__ X, long long n, int d, int D2, int D2P,
-                                 float scale, float* __restrict__ Xp, int ld,
-                                 float* __restrict__ norms, long long n_pad,
-                                 unsigned* __restrict__ maxnorm_bits) {
-    long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= n_pad) return;
-    const int rowf = 2 * D2P;
-    float* dst = Xp + row * ld;
-    if (row >= n) {
-        for (int c = 0; c < ld; ++c) dst[c] = 0.0f;
-        if (norms) norms[row] = __uint_as_float(0x7f000000u);  // finite, above every real score
-        return;
+// One block packs PACK_ROWS consecutive rows: the rows are read as one contiguous, coalesced
+// range into LDS, then written out column by column in the packed order (coalesced again);
+// one thread per row runs the norm's fmaf chain out of LDS.  HBM-bound: n*d*4 bytes in,
+// n*ld*4 out.
+static constexpr int PACK_ROWS = 64;
+__global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict__ X, long long n, int d, int D2,
+                                                        int D2P, float scale, float* __restrict__ Xp, int ld,
+                                                        float* __restrict__ norms, long long n_pad,
+                                                        unsigned* __restrict__ maxnorm_bits) {
+    __shared__ float rows[PACK_ROWS * SCMIAC_KNN_MAX_D_INTERNAL];
+    const long long row0 = (long long)blockIdx.x * PACK_ROWS;
+    if (row0 >= n_pad) return;
+    const int nrows = (int)((n_pad - row0) < PACK_ROWS ? (n_pad - row0) : PACK_ROWS);
+    const long long real = n - row0;  // rows of this block that exist in X (may be <= 0)
+    const int nreal = real < 0 ? 0 : (real < nrows ? (int)real : nrows);
+    const float* src = X + row0 * d;
+    for (int i = threadIdx.x; i < nreal * d; i += blockDim.x) rows[i] = src[i];
+    __syncthreads();
+    float* dst = Xp + row0 * ld;
+    for (int i = threadIdx.x; i < nrows * ld; i += blockDim.x) {
+        const int r = i / ld, c = i - r * ld;
+        const int h = c / D2P, s = c - h * D2P;
+        const int f = h * D2 + s;
+        float v = 0.0f;
+        if (r < nreal && h < 2 && s < D2 && f < d) v = rows[r * d + f] * scale;
+        dst[i] = v;
     }
-    const float* src = X + row * d;
-    for (int h = 0; h < 2; ++h) {
-        for (int s = 0; s < D2P; ++s) {
-            int f = h * D2 + s;
-            float v = (s < D2 && f < d) ? src[f] : 0.0f;
-            dst[h * D2P + s] = v * scale;
+    if (norms && (int)threadIdx.x < nrows) {
+        const int r = threadIdx.x;
+        if (r >= nreal) {
+            norms[row0 + r] = __uint_as_float(0x7f000000u);  // finite, above every real score
+        } else {
+            // rows[] is read with a stride of d floats: conflict-free for odd d, a few-way
+            // conflict otherwise -- irrelevant next to the HBM traffic
+            float acc = 0.0f;
+            for (int i = 0; i < d; ++i) acc = __fmaf_rn(rows[r * d + i], rows[r * d + i], acc);
+            norms[row0 + r] = acc;
+            atomicMax(maxnorm_bits, __float_as_uint(acc));  // acc >= 0: bit order == value order
         }
-    }
-    for (int c = rowf; c < ld; ++c) dst[c] = 0.0f;
-    if (norms) {
-        float acc = 0.0f;
-        for (int i = 0; i < d; ++i) acc = __fmaf_rn(src[i], src[i], acc);
-        norms[row] = acc;
-        atomicMax(maxnorm_bits, __float_as_uint(acc));  // acc >= 0: bit order == value order
     }
 }
 
@@ -994,7 +1006,7 @@ KnnGeometry knn_geometry(long long n, long long m, int d, int k, int splits) {
 
 hipError_t launch_pack(const float* X, long long n, int d, const KnnGeometry& g, float scale, float* Xp,
                        int ld, float* norms, long long n_pad, unsigned* maxnorm_bits, hipStream_t stream) {
-    dim3 block(256), grid((unsigned)((n_pad + 255) / 256));
+    dim3 block(256), grid((unsigned)((n_pad + PACK_ROWS - 1) / PACK_ROWS));
     hipLaunchKernelGGL(pack_rows_kernel, grid, block, 0, stream, X, n, d, g.D2, g.D2P, scale, Xp, ld, norms,
                        n_pad, maxnorm_bits);
     return hipGetLastError();
