@@ -254,7 +254,10 @@ __device__ __forceinline__ float flush_query(unsigned c0, unsigned c1, const uin
 }
 
 template <int D2, int NW_, int RT_, int PCAP_, bool GP_, bool DIAG_>
-__global__ __launch_bounds__(NW_ * 64, (NW_ >= 8 ? NW_ / 4 : 2)) void fused_knn_kernel(
+__global__ __launch_bounds__(NW_ * 64, (NW_ >= 8 ? NW_ / 4 : 2))
+// exactly this many waves per SIMD: the LDS allows one block per CU, so registers saved
+// beyond that buy nothing, and the scheduler should not trade LDS-read lookahead for them
+__attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4 : 2)))) void fused_knn_kernel(
     const float* __restrict__ Qp,     // [n_pad][ROWF], already scaled by -2
     const float* __restrict__ Rp,     // [m_pad][LS], zero pad columns
     const float* __restrict__ rnorm,  // [m_pad], 1.7e38 on padding rows
@@ -276,7 +279,6 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ >= 8 ? NW_ / 4 : 2)) void fused_knn_
     constexpr int NORM_CHUNKS = RT / 64;        // 256 B = one wave-wide 4-byte LDS-DMA load
     static_assert(STAGE_BYTES % 1024 == 0, "a stage is a whole number of wave-wide loads");
     static_assert(RT % 64 == 0 && NORM_CHUNKS <= NW, "norms of a stage: one load per wave at most");
-    static_assert(NSUB % 2 == 0, "two accumulator sets alternate within a stage");
     (void)ROWF;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -487,12 +489,17 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ >= 8 ? NW_ / 4 : 2)) void fused_knn_
         if (diag) dg_slow += (u64)clock64() - ts0;
     };
 
-    // Software pipeline over subtiles (32 references each).  While the MFMA chain of
-    // subtile s runs, the wave issues the threshold test of subtile s-1 (other
-    // accumulator set) and the LDS reads of subtile s+1 (other fragment set).
-    constexpr int HEAD = D2 < 4 ? D2 : 4;  // MFMAs issued before the previous subtile's test
+    // Software pipeline over subtiles (32 references each) and, within a subtile, over groups
+    // of four MFMA steps.  The A-operand fragments live in a ring of three four-register
+    // groups: the LDS read for group g + 2 is issued just before the MFMAs of group g (two
+    // groups = eight MFMAs ahead, far more than the LDS latency), running on into the next
+    // subtile's first groups.  A whole double-buffered fragment set would cost 44 more VGPRs,
+    // and with them the compiler's freedom to place these reads.  While subtile s's chain
+    // runs, the wave also tests subtile s-1 (other accumulator set) after its first group.
+    constexpr int NGRP = D2P / 4;  // groups of four steps (the last one may be partly padding)
+    static_assert(NGRP >= 2, "two groups of lookahead");
     f32x16 accs[2];
-    float rfr[2][D2P];
+    float fr[3][4];
     unsigned ref0s[2] = {0u, 0u};
 #pragma unroll
     for (int r = 0; r < 16; ++r) accs[1][r] = tau_max;  // "previous subtile" of the first one
@@ -500,14 +507,11 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ >= 8 ? NW_ / 4 : 2)) void fused_knn_
     const bool do_stage = !(ablate & 2);  // diagnostic: keep re-reading the first stage
     const bool do_sync = !(ablate & 4);   // diagnostic: no block barrier (results are garbage)
 
-#define SCMIAC_LOAD_FRAGS(DST_, TB_, SUB_)                                                          \
+// ring slot SLOT_ <- steps 4 G_ .. 4 G_ + 3 of subtile SUB_'s fragments
+#define SCMIAC_LOAD_GROUP(SUB_, G_, SLOT_)                                                          \
     do {                                                                                            \
-        const float* ap_ = (TB_) + ((SUB_) * 32 + j) * LS + hh * D2P;                               \
-        _Pragma("unroll") for (int c = 0; c < D2P / 4; ++c) {                                       \
-            float4 v = lds_read_b128(ap_ + 4 * c);                                                  \
-            (DST_)[4 * c + 0] = v.x; (DST_)[4 * c + 1] = v.y;                                       \
-            (DST_)[4 * c + 2] = v.z; (DST_)[4 * c + 3] = v.w;                                       \
-        }                                                                                           \
+        float4 v = lds_read_b128(tb + ((SUB_) * 32 + j) * LS + hh * D2P + 4 * (G_));                \
+        fr[SLOT_][0] = v.x; fr[SLOT_][1] = v.y; fr[SLOT_][2] = v.z; fr[SLOT_][3] = v.w;             \
     } while (0)
 // accumulator set SET_ <- |r|^2 of subtile SUB_ (the MFMA chain then adds -2 q.r on top)
 #define SCMIAC_LOAD_NORMS(SET_, SUB_)                                                               \
@@ -518,31 +522,46 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ >= 8 ? NW_ / 4 : 2)) void fused_knn_
             accs[SET_][4 * g + 2] = nv.z; accs[SET_][4 * g + 3] = nv.w;                             \
         }                                                                                           \
     } while (0)
-// One subtile: CUR_/PRV_ are the compile-time indices of the two register sets.  On entry
-// accs[CUR_] holds the subtile's |r|^2 and rfr[CUR_] its fragments, both fetched while the
-// previous subtile's chain ran, so the first MFMA follows the previous chain's last one
-// without an LDS wait (the three waves of a SIMD run in step and would all be waiting at
-// the same time).  The previous subtile's scores are tested after the first MFMAs; once
-// they are dealt with, their registers take the next subtile's |r|^2 and fragments.
+// One subtile: CUR_/PRV_ are the compile-time indices of the two accumulator sets.  On entry
+// accs[CUR_] holds the subtile's |r|^2 and the ring its first two fragment groups, all
+// fetched while the previous subtile's chain ran, so the first MFMA follows the previous
+// chain's last one without an LDS wait (the waves of a SIMD run in step and would all be
+// waiting at the same time).  The previous subtile's scores are tested after the first
+// group; once they are dealt with, their registers take the next subtile's |r|^2.
+// one group of a subtile's chain: the LDS read two groups ahead, then this group's MFMAs
+#define SCMIAC_GROUP(CUR_, SUB_, G_)                                                                \
+    do {                                                                                            \
+        const int ph_ = ((SUB_) * NGRP) % 3; /* ring slot of this subtile's group 0 */              \
+        if ((G_) + 2 < NGRP) SCMIAC_LOAD_GROUP((SUB_), (G_) + 2, (ph_ + (G_) + 2) % 3);             \
+        else if ((SUB_) + 1 < NSUB) SCMIAC_LOAD_GROUP((SUB_) + 1, (G_) + 2 - NGRP, (ph_ + (G_) + 2) % 3); \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e)                                               \
+            if (4 * (G_) + e < D2)                                                                  \
+                accs[CUR_] = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[(ph_ + (G_)) % 3][e], qf[4 * (G_) + e], \
+                                                                  accs[CUR_], 0, 0, 0);             \
+        /* tell the scheduler to keep this order: the LDS read, then this group's MFMAs */          \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                          \
+        if (4 * (G_) + 4 <= D2) __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                  \
+        else __builtin_amdgcn_sched_group_barrier(0x008, (D2 % 4) ? (D2 % 4) : 4, 0);               \
+    } while (0)
 #define SCMIAC_SUBTILE(CUR_, PRV_, SUB_)                                                            \
     do {                                                                                            \
-        _Pragma("unroll") for (int s = 0; s < HEAD; ++s)                                            \
-            accs[CUR_] = __builtin_amdgcn_mfma_f32_32x32x2f32(rfr[CUR_][s], qf[s], accs[CUR_], 0, 0, 0); \
-        /* smallest of the 16 scores as a depth-3 tree: a wave waits its turn for every */          \
-        /* instruction that depends on the one before, so depth costs more than count   */          \
-        const float m0_ = min3_after_mfma(accs[PRV_][0], accs[PRV_][1], accs[PRV_][2]);             \
-        const float m1_ = min3_raw_after(accs[PRV_][3], accs[PRV_][4], accs[PRV_][5], m0_);         \
-        const float m2_ = min3_raw_after(accs[PRV_][6], accs[PRV_][7], accs[PRV_][8], m0_);         \
-        const float m3_ = min3_raw_after(accs[PRV_][9], accs[PRV_][10], accs[PRV_][11], m0_);       \
-        const float m4_ = min3_raw_after(accs[PRV_][12], accs[PRV_][13], accs[PRV_][14], m0_);      \
-        const float mn_ = min2_raw(min3_raw(m0_, m1_, m2_), min3_raw(m3_, m4_, accs[PRV_][15]));    \
-        if (__any(mn_ < tau_hi)) select_slow(accs[PRV_], ref0s[PRV_]);                              \
-        if ((SUB_) + 1 < NSUB) {                                                                    \
-            SCMIAC_LOAD_NORMS(PRV_, (SUB_) + 1);                                                    \
-            SCMIAC_LOAD_FRAGS(rfr[PRV_], tb, (SUB_) + 1);                                           \
+        SCMIAC_GROUP(CUR_, SUB_, 0);                                                                \
+        {                                                                                           \
+            /* smallest of the 16 scores as a depth-3 tree: a wave waits its turn for every */      \
+            /* instruction that depends on the one before: depth costs, not count           */      \
+            const float m0_ = min3_after_mfma(accs[PRV_][0], accs[PRV_][1], accs[PRV_][2]);         \
+            const float m1_ = min3_raw_after(accs[PRV_][3], accs[PRV_][4], accs[PRV_][5], m0_);     \
+            const float m2_ = min3_raw_after(accs[PRV_][6], accs[PRV_][7], accs[PRV_][8], m0_);     \
+            const float m3_ = min3_raw_after(accs[PRV_][9], accs[PRV_][10], accs[PRV_][11], m0_);   \
+            const float m4_ = min3_raw_after(accs[PRV_][12], accs[PRV_][13], accs[PRV_][14], m0_);  \
+            const float mn_ = min2_raw(min3_raw(m0_, m1_, m2_), min3_raw(m3_, m4_, accs[PRV_][15])); \
+            if (__any(mn_ < tau_hi)) select_slow(accs[PRV_], ref0s[PRV_]);                          \
+            if ((SUB_) + 1 < NSUB) {                                                                \
+                SCMIAC_LOAD_NORMS(PRV_, (SUB_) + 1);                                                \
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                  \
+            }                                                                                       \
         }                                                                                           \
-        _Pragma("unroll") for (int s = HEAD; s < D2; ++s)                                           \
-            accs[CUR_] = __builtin_amdgcn_mfma_f32_32x32x2f32(rfr[CUR_][s], qf[s], accs[CUR_], 0, 0, 0); \
+        _Pragma("unroll") for (int g = 1; g < NGRP; ++g) SCMIAC_GROUP(CUR_, SUB_, g);               \
         ref0s[CUR_] = (unsigned)(r_begin + (long long)t * RT + (SUB_) * 32); /* wave-uniform */     \
     } while (0)
 
@@ -557,11 +576,22 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ >= 8 ? NW_ / 4 : 2)) void fused_knn_
             // |r|^2 and fragments of the stage's first subtile (the stage only became readable at
             // the barrier; set 0 was tested during the previous stage's last subtile)
             SCMIAC_LOAD_NORMS(0, 0);
-            SCMIAC_LOAD_FRAGS(rfr[0], tb, 0);
-#pragma unroll
-            for (int sp = 0; sp < NSUB; sp += 2) {
-                SCMIAC_SUBTILE(0, 1, sp);
-                SCMIAC_SUBTILE(1, 0, sp + 1);
+            SCMIAC_LOAD_GROUP(0, 0, 0);
+            SCMIAC_LOAD_GROUP(0, 1, 1);
+            // the subtiles of a stage, written out: their numbers must be compile-time constants
+            // (ring slots, LDS offsets), whatever the optimizer thinks of unrolling a loop this big
+            static_assert(NSUB == 2 || NSUB == 4 || NSUB == 8, "stage of 64, 128 or 256 rows");
+            SCMIAC_SUBTILE(0, 1, 0);
+            SCMIAC_SUBTILE(1, 0, 1);
+            if constexpr (NSUB > 2) {
+                SCMIAC_SUBTILE(0, 1, 2);
+                SCMIAC_SUBTILE(1, 0, 3);
+            }
+            if constexpr (NSUB > 4) {
+                SCMIAC_SUBTILE(0, 1, 4);
+                SCMIAC_SUBTILE(1, 0, 5);
+                SCMIAC_SUBTILE(0, 1, 6);
+                SCMIAC_SUBTILE(1, 0, 7);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA loads have landed
             if (do_sync) __syncthreads();
@@ -581,9 +611,10 @@ __global__ __launch_bounds__(NW_ * 64, (NW_ >= 8 ? NW_ / 4 : 2)) void fused_knn_
         o[8] = dg_seg2; o[9] = dg_ngen; o[10] = 0; o[11] = 0;
     }
 #undef SCMIAC_STAGE
-#undef SCMIAC_LOAD_FRAGS
+#undef SCMIAC_LOAD_GROUP
 #undef SCMIAC_LOAD_NORMS
 #undef SCMIAC_SUBTILE
+#undef SCMIAC_GROUP
 }
 
 // --------------------------------------------------------------------------------
