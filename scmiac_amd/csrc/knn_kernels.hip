@@ -555,7 +555,7 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
             const float m3_ = min3_raw_after(accs[PRV_][9], accs[PRV_][10], accs[PRV_][11], m0_);   \
             const float m4_ = min3_raw_after(accs[PRV_][12], accs[PRV_][13], accs[PRV_][14], m0_);  \
             const float mn_ = min2_raw(min3_raw(m0_, m1_, m2_), min3_raw(m3_, m4_, accs[PRV_][15])); \
-            if (__any(mn_ < tau_hi)) select_slow(accs[PRV_], ref0s[PRV_]);                          \
+            if (__builtin_expect(__any(mn_ < tau_hi), 0)) select_slow(accs[PRV_], ref0s[PRV_]);     \
             if ((SUB_) + 1 < NSUB) {                                                                \
                 SCMIAC_LOAD_NORMS(PRV_, (SUB_) + 1);                                                \
                 __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                  \
