@@ -413,10 +413,10 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
 #pragma unroll
         for (int r = 0; r < 16; ++r) key[r] = score_key(sc[r], r);
         // smallest key of the lane, as a depth-3 tree (every dependent step costs a turn)
-        const float a0 = fminf(fminf(key[0], key[1]), key[2]), a1 = fminf(fminf(key[3], key[4]), key[5]);
-        const float a2 = fminf(fminf(key[6], key[7]), key[8]), a3 = fminf(fminf(key[9], key[10]), key[11]);
-        const float a4 = fminf(fminf(key[12], key[13]), key[14]);
-        const float kmin = fminf(fminf(fminf(a0, a1), a2), fminf(fminf(a3, a4), key[15]));
+        const float a0 = min3_raw(key[0], key[1], key[2]), a1 = min3_raw(key[3], key[4], key[5]);
+        const float a2 = min3_raw(key[6], key[7], key[8]), a3 = min3_raw(key[9], key[10], key[11]);
+        const float a4 = min3_raw(key[12], key[13], key[14]);
+        const float kmin = min2_raw(min3_raw(a0, a1, a2), min3_raw(a3, a4, key[15]));
         // does any lane have two keys below its threshold?  Scalar bookkeeping on the compare
         // masks, four registers at a time and then across the four groups: a single chain
         // over all sixteen would be 32 scalar instructions each waiting for the one before.
@@ -437,13 +437,13 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
             asm volatile("" ::"v"(kmin), "s"(twice));
             return;
         }
-        if (twice == 0ull) {
+        if (__builtin_expect(twice == 0ull, 1)) {
             // the usual case: at most one candidate per lane, and it is the lane's smallest key
             // (key register r holds subtile row (r & 3) + 8 (r >> 2) = r + (r & 12))
             const unsigned kb = __float_as_uint(kmin);
             const uint2 entry = make_uint2(kb, ref0 + (kb & 15u) + (kb & 12u));
             const bool p = kmin < tau;
-            if (__any(p && pcnt >= (unsigned)HCAP)) {  // rare: make room first, then test again
+            if (__builtin_expect(__any(p && pcnt >= (unsigned)HCAP), 0)) {  // rare: make room first, then test again
                 flush_full(true, false);
                 if (p && kmin < tau) { pend_l[pcnt] = entry; ++pcnt; }
             } else if (p) {
