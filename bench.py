@@ -49,6 +49,9 @@ WORKLOADS = {
     # one GPU's share of the 4M x 2M, d=64 cosine atlas on 8 GPUs: its 500k query rows against all 2M
     # reference rows (what the ring delivers block by block); rows L2-normalised, so Euclidean = cosine order
     "c5shard": (500_000, 2_000_000, 64, 200, (5000, 5001, 5002)),
+    # a wide embedding (tuning aid for the d > 64 kernel variants)
+    "wide": (200_000, 500_000, 100, 100, (7000, 7001, 7002)),
+    "wide128": (200_000, 500_000, 128, 100, (7100, 7101, 7102)),
 }
 UNIT_NORM = {"c5shard"}
 

@@ -868,6 +868,7 @@ static const int kD2Sizes[] = {8, 15, 16, 20, 25, 32, 40, 50, 64};
 #define SCMIAC_FUSED_VARIANTS(X) \
     X(8, 12, 256, 32, 1) X(15, 12, 256, 32, 1) X(16, 12, 256, 32, 1) X(20, 12, 256, 32, 1) X(25, 12, 256, 32, 1) \
     X(32, 12, 256, 32, 1) X(40, 8, 64, 32, 0) X(50, 8, 64, 32, 0) X(64, 8, 64, 32, 0) \
+    X(40, 12, 128, 32, 1) X(50, 12, 128, 32, 1) X(64, 8, 128, 32, 1) \
     X(25, 12, 128, 32, 0) X(25, 12, 128, 32, 1) X(32, 12, 128, 24, 0) X(25, 12, 256, 16, 1)
 
 int knn_pick_d2(int d) {
@@ -894,17 +895,17 @@ static hipError_t launch_fused_t(const float* Qp, const float* Rp, const float* 
 
 // (waves per block, reference rows per LDS stage) of the fused kernel
 static void fused_variant(int D2, int* nw, int* rt, int* pcap, int* gp) {
-    // Up to 64 features: 12 waves per block (3 per SIMD), the pending-candidate buffers in
-    // global memory and all of the LDS given to two 256-row stages (fewer barriers, and the
-    // waves' uneven candidate work averages out over a longer stage).  Wider rows: 8 waves,
-    // 64-row stages, buffers in LDS.
-    *nw = (D2 <= 32) ? 12 : 8;
-    *rt = (D2 <= 32) ? 256 : 64;
+    // 12 waves per block (3 per SIMD) wherever the registers allow (up to 100 features), the
+    // pending-candidate buffers in global memory and all of the LDS given to two stages as
+    // long as it holds: 256 rows up to 64 features, 128 beyond (fewer barriers, and the
+    // waves' uneven candidate work averages out over a longer stage).
+    *nw = (D2 <= 50) ? 12 : 8;
+    *rt = (D2 <= 32) ? 256 : 128;
     *pcap = 32;
-    *gp = (D2 <= 32) ? 1 : 0;
+    *gp = 1;
     if (const char* v = getenv("SCMIAC_FUSED_VARIANT")) {  // tuning aid: "NWxRTxPCAPxGP", e.g. 12x256x32x1
         int a = 0, b = 0, c = 32, e = 0;
-        if (sscanf(v, "%dx%dx%dx%d", &a, &b, &c, &e) >= 2 && (D2 == 25 || D2 == 32)) {
+        if (sscanf(v, "%dx%dx%dx%d", &a, &b, &c, &e) >= 2) {  // (the combination must be a compiled one)
             *nw = a; *rt = b; *pcap = c; *gp = e;
         }
     }
