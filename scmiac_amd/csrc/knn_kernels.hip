@@ -867,9 +867,9 @@ static const int kD2Sizes[] = {8, 15, 16, 20, 25, 32, 40, 50, 64};
 // pending candidates in global memory)
 #define SCMIAC_FUSED_VARIANTS(X) \
     X(8, 12, 256, 32, 1) X(15, 12, 256, 32, 1) X(16, 12, 256, 32, 1) X(20, 12, 256, 32, 1) X(25, 12, 256, 32, 1) \
-    X(32, 12, 256, 32, 1) X(40, 8, 64, 32, 0) X(50, 8, 64, 32, 0) X(64, 8, 64, 32, 0) \
+    X(32, 12, 256, 32, 1) \
     X(40, 12, 128, 32, 1) X(50, 12, 128, 32, 1) X(64, 8, 128, 32, 1) \
-    X(25, 12, 128, 32, 0) X(25, 12, 128, 32, 1) X(32, 12, 128, 24, 0) X(25, 12, 256, 16, 1)
+    X(25, 12, 128, 32, 0) X(25, 12, 128, 32, 1) X(25, 12, 256, 16, 1)
 
 int knn_pick_d2(int d) {
     int need = (d + 1) / 2;
