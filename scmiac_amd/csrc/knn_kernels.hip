@@ -580,7 +580,7 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
             SCMIAC_LOAD_GROUP(0, 1, 1);
             // the subtiles of a stage, written out: their numbers must be compile-time constants
             // (ring slots, LDS offsets), whatever the optimizer thinks of unrolling a loop this big
-            static_assert(NSUB == 2 || NSUB == 4 || NSUB == 8, "stage of 64, 128 or 256 rows");
+            static_assert(NSUB == 2 || NSUB == 4 || NSUB == 8 || NSUB == 10, "stage of 64, 128, 256 or 320 rows");
             SCMIAC_SUBTILE(0, 1, 0);
             SCMIAC_SUBTILE(1, 0, 1);
             if constexpr (NSUB > 2) {
@@ -592,6 +592,10 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
                 SCMIAC_SUBTILE(1, 0, 5);
                 SCMIAC_SUBTILE(0, 1, 6);
                 SCMIAC_SUBTILE(1, 0, 7);
+            }
+            if constexpr (NSUB > 8) {
+                SCMIAC_SUBTILE(0, 1, 8);
+                SCMIAC_SUBTILE(1, 0, 9);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA loads have landed
             if (do_sync) __syncthreads();
@@ -866,10 +870,10 @@ static const int kD2Sizes[] = {8, 15, 16, 20, 25, 32, 40, 50, 64};
 // compiled (D2, waves per block, reference rows per LDS stage, pending candidates per query,
 // pending candidates in global memory)
 #define SCMIAC_FUSED_VARIANTS(X) \
-    X(8, 12, 256, 32, 1) X(15, 12, 256, 32, 1) X(16, 12, 256, 32, 1) X(20, 12, 256, 32, 1) X(25, 12, 256, 32, 1) \
+    X(8, 12, 320, 32, 1) X(15, 12, 320, 32, 1) X(16, 12, 320, 32, 1) X(20, 12, 320, 32, 1) X(25, 12, 320, 32, 1) \
     X(32, 12, 256, 32, 1) \
     X(40, 12, 128, 32, 1) X(50, 12, 128, 32, 1) X(64, 8, 128, 32, 1) \
-    X(25, 12, 128, 32, 0) X(25, 12, 128, 32, 1) X(25, 12, 256, 16, 1)
+    X(25, 12, 128, 32, 0) X(25, 12, 128, 32, 1) X(25, 12, 256, 16, 1) X(25, 12, 256, 32, 1)
 
 int knn_pick_d2(int d) {
     int need = (d + 1) / 2;
@@ -897,10 +901,10 @@ static hipError_t launch_fused_t(const float* Qp, const float* Rp, const float* 
 static void fused_variant(int D2, int* nw, int* rt, int* pcap, int* gp) {
     // 12 waves per block (3 per SIMD) wherever the registers allow (up to 100 features), the
     // pending-candidate buffers in global memory and all of the LDS given to two stages as
-    // long as it holds: 256 rows up to 64 features, 128 beyond (fewer barriers, and the
-    // waves' uneven candidate work averages out over a longer stage).
+    // long as it holds: 320 rows up to 50 features, 256 up to 64, 128 beyond (fewer barriers,
+    // and the waves' uneven candidate work averages out over a longer stage).
     *nw = (D2 <= 50) ? 12 : 8;
-    *rt = (D2 <= 32) ? 256 : 128;
+    *rt = (D2 <= 25) ? 320 : (D2 <= 32) ? 256 : 128;
     *pcap = 32;
     *gp = 1;
     if (const char* v = getenv("SCMIAC_FUSED_VARIANT")) {  // tuning aid: "NWxRTxPCAPxGP", e.g. 12x256x32x1
