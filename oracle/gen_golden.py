@@ -103,14 +103,45 @@ def quiet(fn, *a, **kw):
     return out, buf.getvalue()
 
 
+def cca_fixture(ref, out):
+    """F5: the reference's ``cca`` (anchors.py:171-242) on count-like matrices: all cells
+    in the decomposition (both orientations), and more cells than ``max_cc_cell`` on both
+    sides (sub-sample + chunked projection, with the feature selection of ``k_filter``)."""
+    rng = np.random.default_rng(77)
+    f5 = {}
+    cases = {"a": (500, 420, 90, 16, 50000, 50000, None),    # n1 > n2
+             "b": (380, 520, 90, 16, 50000, 50000, None),    # n1 < n2: transposed inside the SVD
+             "c": (900, 800, 110, 24, 500, 300, 200),        # both sides sub-sampled
+             "d": (300, 700, 80, 12, 400, 256, None)}        # one side sub-sampled
+    for tag, (n1, n2, g, nc, cap, chunk, kf) in cases.items():
+        prof = rng.gamma(2.0, 1.0, size=(6, g))
+        l1 = rng.integers(0, 6, n1)
+        l2 = rng.integers(0, 6, n2)
+        X1 = np.log1p(rng.poisson(prof[l1] * 2.0)).astype(np.float64)
+        X2 = np.log1p(rng.poisson(prof[l2] * 1.5)).astype(np.float64)
+        X1[:, 3] = 0.0  # a gene with no counts: constant column through the scaler
+        (U, V, hdf), _ = quiet(ref.cca, X1, X2, scale1=True, scale2=(tag != "d"), n_components=nc,
+                               max_cc_cell=cap, chunk_size=chunk, random_state=0, k_filter=kf)
+        f5[f"{tag}_X1"], f5[f"{tag}_X2"] = X1, X2
+        f5[f"{tag}_args"] = np.array([nc, cap, chunk, kf if kf else 0, int(tag != "d")], dtype=np.int64)
+        f5[f"{tag}_U"], f5[f"{tag}_V"] = np.asarray(U, np.float64), np.asarray(V, np.float64)
+        if hdf is not None:
+            f5[f"{tag}_hdf"] = np.asarray(hdf, dtype=np.int64)
+    np.savez_compressed(out / "f5_cca.npz", **f5)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--out", default=str(ROOT / "tests" / "golden"))
+    ap.add_argument("--only", default="", help="'f5': regenerate only the CCA fixture")
     args = ap.parse_args()
     out = Path(args.out)
     out.mkdir(parents=True, exist_ok=True)
     ref, scm = load_reference(Path(args.ref))
+    if args.only == "f5":
+        cca_fixture(ref, out)
+        return
 
     # ---- F1: find_mnn on random tables (duplicates inside rows allowed) --------
     rng = np.random.default_rng(11)
@@ -257,6 +288,7 @@ def main():
               cca_x1=cdf["x1"].values.astype(np.int64), cca_x2=cdf["x2"].values.astype(np.int64),
               cca_score=cdf["score"].values.astype(np.float64))
     np.savez_compressed(out / "f4_find_anchor.npz", **f4)
+    cca_fixture(ref, out)
 
     for f in sorted(out.glob("*.npz")):
         print(f.name, f.stat().st_size)

@@ -228,6 +228,69 @@ def score_anchor(anchor, G11, G12, G21, G22, k_score=30, Gp1=None, Gp2=None, k_l
     return anchor_df
 
 
+# ---------------------------------------------------------------- upstream producer
+def top_loading_features(data, n_features):
+    """Genes with the largest absolute loadings over the components (anchors.py:132-168)."""
+    n_cc = data.shape[0]
+    per_dim = min(n_features * 10 // n_cc, data.shape[1] - 1)
+    rows = np.arange(n_cc)[:, None]
+    data = np.abs(data)
+    idx = np.argpartition(-data, per_dim, axis=1)[:, :per_dim]
+    idx = idx[rows, np.argsort(-data[rows, idx], axis=1)]
+    for i in range(n_features // n_cc + 1, per_dim):
+        features_idx = np.unique(idx[:, :i].flatten())
+        if len(features_idx) > n_features:
+            return features_idx
+    return np.unique(idx[:, :per_dim].flatten())
+
+
+def cca(data1, data2, scale1=True, scale2=True, n_components=50, max_cc_cell=20000, chunk_size=50000,
+        random_state=0, k_filter=None, n_features=200):
+    """Canonical correlation vectors as the reference computes them (anchors.py:171-242
+    with the sub-sampling of 480-507): scikit-learn's StandardScaler and randomized
+    TruncatedSVD on the dense ``X1 @ X2.T``; cells beyond ``max_cc_cell`` are projected
+    afterwards in chunks.  Dense inputs only."""
+    from sklearn.decomposition import TruncatedSVD
+    from sklearn.preprocessing import StandardScaler
+
+    np.random.seed(random_state)
+    np.random.seed(random_state)
+    sub, scalers = [], []
+    for data, scale in ((data1, scale1), (data2, scale2)):
+        n = data.shape[0]
+        tf = data[np.random.choice(np.arange(n), max_cc_cell, False)] if n > max_cc_cell else data.copy()
+        sub.append(np.asarray(tf, dtype=np.float64))
+    for pos, scale in enumerate((scale1, scale2)):
+        scalers.append(StandardScaler() if scale else None)
+        if scale:
+            sub[pos] = scalers[pos].fit_transform(sub[pos])
+    tf1, tf2 = sub
+
+    model = TruncatedSVD(n_components=n_components, algorithm="randomized", random_state=random_state)
+    U = model.fit_transform(tf1.dot(tf2.T.copy()))
+    keep = model.singular_values_ != 0
+    sv = model.singular_values_[keep]
+    V = model.components_[keep].T
+    U = U[:, keep] / sv
+    features = None
+    if k_filter:
+        features = top_loading_features(
+            np.concatenate([U, V], axis=0).T.dot(np.concatenate([tf1, tf2], axis=0)), n_features)
+
+    def chunks(data, scaler):
+        for start in range(0, data.shape[0], chunk_size):
+            tmp = np.asarray(data[start:start + chunk_size], dtype=np.float64)
+            yield scaler.transform(tmp) if scaler is not None else tmp
+
+    if data2.shape[0] > max_cc_cell:
+        left = np.dot(U.T, tf1)
+        V = np.concatenate([np.dot(left, tmp.T).T for tmp in chunks(data2, scalers[1])], axis=0) / sv
+    if data1.shape[0] > max_cc_cell:
+        right = np.dot(model.components_[keep], tf2).T
+        U = np.concatenate([np.dot(tmp, right) for tmp in chunks(data1, scalers[0])], axis=0) / sv
+    return U, V, features
+
+
 # ------------------------------------------------------------ pairwise orchestration
 def l2_normalize_rows(X):
     """sklearn.preprocessing.normalize(X, axis=1) for dense input

@@ -172,7 +172,7 @@ def filter_anchor(anchor, adata_ref=None, adata_qry=None, scale_ref=False, scale
     return anchor
 
 
-# ------------------------------------------------------- upstream producer (host)
+# -------------------------------------------------------------- upstream producer
 def downsample(data1, data2, scale1, scale2, todense, max_cc_cell=20000, random_state=0):
     """Cell subsampling + optional standardisation before CCA (anchors.py:480-507)."""
     from scipy.sparse import issparse
@@ -200,49 +200,17 @@ def downsample(data1, data2, scale1, scale2, todense, max_cc_cell=20000, random_
 def cca(data1, data2, scale1=True, scale2=True, n_components=50, max_cc_cell=20000, chunk_size=50000,
         random_state=0, svd_algorithm="randomized", k_filter=None, n_features=200):
     """Canonical correlation vectors by truncated SVD of ``X1 @ X2.T``
-    (anchors.py:171-242).  Host computation (scikit-learn), as in the reference:
-    it produces the embeddings the GPU search consumes."""
-    from scipy.sparse import issparse
-    from sklearn.decomposition import TruncatedSVD
+    (anchors.py:171-242), on the GPU and without forming the cell x cell matrix
+    (:mod:`scmiac_amd.cca_device`).  Returns ``(U, V, high_dim_feature)`` as float64
+    numpy arrays.  Only the reference's default ``svd_algorithm="randomized"`` is
+    provided."""
+    from ..cca_device import cca_device
 
-    np.random.seed(random_state)
-    tf_data1, tf_data2, scaler1, scaler2 = downsample(
-        data1=data1, data2=data2, todense=True, scale1=scale1, scale2=scale2,
-        max_cc_cell=max_cc_cell, random_state=random_state)
-
-    model = TruncatedSVD(n_components=n_components, algorithm=svd_algorithm, random_state=random_state)
-    tf_data2_t = tf_data2.T.copy()
-    U = model.fit_transform(tf_data1.dot(tf_data2_t))
-
-    sel_dim = model.singular_values_ != 0
-    print("non zero dims", sel_dim.sum())
-
-    V = model.components_[sel_dim].T
-    U = U[:, sel_dim] / model.singular_values_[sel_dim]
-
-    if k_filter:
-        high_dim_feature = top_features_idx(
-            np.concatenate([U, V], axis=0).T.dot(np.concatenate([tf_data1, tf_data2], axis=0)),
-            n_features=n_features)
-    else:
-        high_dim_feature = None
-
-    def _project(data, scaler, scale, left):
-        parts = []
-        for chunk_start in np.arange(0, data.shape[0], chunk_size):
-            tmp = data[chunk_start:(chunk_start + chunk_size)]
-            if issparse(tmp):
-                tmp = tmp.toarray()
-            if scale:
-                tmp = scaler.transform(tmp)
-            parts.append(left(tmp))
-        return np.concatenate(parts, axis=0) / model.singular_values_[sel_dim]
-
-    if data2.shape[0] > max_cc_cell:
-        V = _project(data2, scaler2, scale2, lambda tmp: np.dot(np.dot(U.T, tf_data1), tmp.T).T)
-    if data1.shape[0] > max_cc_cell:
-        U = _project(data1, scaler1, scale1, lambda tmp: np.dot(tmp, np.dot(model.components_[sel_dim], tf_data2).T))
-    return U, V, high_dim_feature
+    if svd_algorithm != "randomized":
+        raise NotImplementedError(f"svd_algorithm={svd_algorithm!r}: only 'randomized' is provided")
+    return cca_device(data1, data2, scale1=scale1, scale2=scale2, n_components=n_components,
+                      max_cc_cell=max_cc_cell, chunk_size=chunk_size, random_state=random_state,
+                      k_filter=k_filter, n_features=n_features)
 
 
 def top_features_idx(data, n_features):

@@ -254,18 +254,55 @@ def test_label_filter_and_csv_golden(golden, ct_filter, tag):
 
 
 def test_find_anchor_cca_branch_golden(golden):
-    """Whole "cca" branch: host CCA (same scikit-learn calls as the reference) feeding
-    the GPU search; anchors and scores must equal the reference's."""
+    """Whole "cca" branch: CCA on the device (matrix-free randomized SVD, float64) feeding
+    the GPU search; U within 1e-10 of the reference's (float64 sums taken in another
+    order), anchors and scores equal to the reference's."""
     f = golden["f4_find_anchor"]
     integ = A.SeuratIntegration()
     integ.find_anchor([_FakeAnnData(f["cca_X1"]), _FakeAnnData(f["cca_X2"])], k_local=None, key_anchor="X",
                       dim_red="cca", max_cc_cells=50000, k_anchor=5, k_score=30, scale1=True, scale2=True,
                       n_components=20, k_filter=None, alignments=[[[0], [1]]])
-    np.testing.assert_allclose(integ.U, f["cca_U"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(integ.U, f["cca_U"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(integ.V, f["cca_V"], rtol=0, atol=1e-10)
     adf = integ.anchor[(0, 1)]
     np.testing.assert_array_equal(adf["x1"].values, f["cca_x1"])
     np.testing.assert_array_equal(adf["x2"].values, f["cca_x2"])
     np.testing.assert_array_equal(adf["score"].values, f["cca_score"])
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_cca_device_golden(golden, tag):
+    """``cca`` on the device against the reference's own ``cca`` (fixture F5): all cells
+    decomposed in both orientations, and the sub-sampled cases with chunked projection.
+    Tolerance 1e-10 absolute on entries of magnitude <= 0.3 (float64 rounding only)."""
+    f = golden["f5_cca"]
+    nc, cap, chunk, kf, scale2 = (int(v) for v in f[f"{tag}_args"])
+    U, V, hdf = A.cca(f[f"{tag}_X1"], f[f"{tag}_X2"], scale1=True, scale2=bool(scale2), n_components=nc,
+                      max_cc_cell=cap, chunk_size=chunk, random_state=0, k_filter=kf or None)
+    assert U.dtype == np.float64 and U.shape == f[f"{tag}_U"].shape and V.shape == f[f"{tag}_V"].shape
+    np.testing.assert_allclose(U, f[f"{tag}_U"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(V, f[f"{tag}_V"], rtol=0, atol=1e-10)
+    if kf:
+        np.testing.assert_array_equal(hdf, f[f"{tag}_hdf"])
+    else:
+        assert hdf is None
+
+
+def test_cca_device_sparse_and_large_against_oracle():
+    """scipy-sparse inputs and more cells than the decomposition keeps, against the CPU
+    restatement (which forms the dense product as the reference does)."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(5)
+    g, n1, n2 = 300, 6000, 5000
+    prof = rng.gamma(2.0, 1.0, size=(8, g))
+    X1 = np.log1p(rng.poisson(prof[rng.integers(0, 8, n1)] * 0.6)).astype(np.float64)
+    X2 = np.log1p(rng.poisson(prof[rng.integers(0, 8, n2)] * 0.4)).astype(np.float64)
+    want = oracle.cca(X1, X2, n_components=30, max_cc_cell=2000, chunk_size=1500)
+    got = A.cca(sp.csr_matrix(X1), sp.csr_matrix(X2), n_components=30, max_cc_cell=2000, chunk_size=1500)
+    np.testing.assert_allclose(got[0], want[0], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(got[1], want[1], rtol=0, atol=1e-9)
+    with pytest.raises(NotImplementedError):
+        A.cca(X1, X2, svd_algorithm="arpack")
 
 
 def test_rare_label_atlas_against_oracle():

@@ -103,3 +103,37 @@ def test_cca_branch_search_matches_reference(golden):
     np.testing.assert_array_equal(df["x1"].values, f["cca_x1"])
     np.testing.assert_array_equal(df["x2"].values, f["cca_x2"])
     np.testing.assert_array_equal(df["score"].values, f["cca_score"])
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_cca_restatement_matches_reference(golden, tag):
+    """The oracle's ``cca`` against the reference's own (fixture F5): same scikit-learn
+    calls on the same dense product, so the agreement is to the last few bits."""
+    f = golden["f5_cca"]
+    nc, cap, chunk, kf, scale2 = (int(v) for v in f[f"{tag}_args"])
+    U, V, hdf = oracle.cca(f[f"{tag}_X1"], f[f"{tag}_X2"], scale1=True, scale2=bool(scale2),
+                           n_components=nc, max_cc_cell=cap, chunk_size=chunk, k_filter=kf or None)
+    np.testing.assert_allclose(U, f[f"{tag}_U"], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(V, f[f"{tag}_V"], rtol=0, atol=1e-13)
+    if kf:
+        np.testing.assert_array_equal(hdf, f[f"{tag}_hdf"])
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_matrix_free_cca_host_logic(golden, tag, monkeypatch):
+    """Host logic of the matrix-free CCA (thin products, LU row permutation, sign
+    convention, sub-sampling, chunked projection) with torch's CPU float64 backend
+    standing in for the device; the GPU run of the same code is a ``gpu`` test."""
+    import torch
+    from scmiac_amd import cca_device
+
+    monkeypatch.setattr(cca_device, "_device", lambda: torch.device("cpu"))
+    f = golden["f5_cca"]
+    nc, cap, chunk, kf, scale2 = (int(v) for v in f[f"{tag}_args"])
+    U, V, hdf = cca_device.cca_device(f[f"{tag}_X1"], f[f"{tag}_X2"], scale1=True, scale2=bool(scale2),
+                                      n_components=nc, max_cc_cell=cap, chunk_size=chunk,
+                                      k_filter=kf or None)
+    np.testing.assert_allclose(U, f[f"{tag}_U"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(V, f[f"{tag}_V"], rtol=0, atol=1e-10)
+    if kf:
+        np.testing.assert_array_equal(hdf, f[f"{tag}_hdf"])
