@@ -185,6 +185,26 @@ SCMIAC_API int scmiac_knn_grid_plan(int64_t n, int64_t m, int d, int k, int spli
 SCMIAC_API int scmiac_knn_set_timing(int enabled);
 SCMIAC_API int scmiac_knn_fused_ms(float *total_ms, int *launches);
 
+/*
+ * Symmetric NT-Xent loss between the two embeddings of a batch of anchor cells:
+ * replaces NTXentLoss2.forward (scmiac/modeling/loss.py:96-133) and its autograd
+ * backward, one launch each.  zi, zj: float32 [batch, d] row-major on the device,
+ * 1 <= d <= 64, batch >= 1.  Rows are L2-normalised inside (x / max(|x|, 1e-12)).
+ *
+ * forward: loss_parts[scmiac_ntxent2_parts(batch)] receives per-block partial sums
+ * whose total is the loss; lse_row / lse_col (float32 [batch]) receive the row and
+ * column log-sum-exp of the similarity matrix, which backward reads.
+ * backward: grad_out points at one float32 on the device (d loss); dzi, dzj receive
+ * d loss / d zi, d loss / d zj.  The batch x batch similarity matrix is recomputed, not
+ * stored.
+ */
+SCMIAC_API int scmiac_ntxent2_parts(int64_t batch);
+SCMIAC_API int scmiac_ntxent2_forward(const float *zi, const float *zj, int64_t batch, int d, float temperature,
+                                      float *lse_row, float *lse_col, float *loss_parts, void *stream);
+SCMIAC_API int scmiac_ntxent2_backward(const float *zi, const float *zj, int64_t batch, int d, float temperature,
+                                       const float *lse_row, const float *lse_col, const float *grad_out,
+                                       float *dzi, float *dzj, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

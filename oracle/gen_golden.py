@@ -130,17 +130,42 @@ def cca_fixture(ref, out):
     np.savez_compressed(out / "f5_cca.npz", **f5)
 
 
+def ntxent_fixture(out):
+    """F6: the reference's ``NTXentLoss2`` (modeling/loss.py:85-133, loaded by
+    ``load_reference``) on the CPU in float32: loss and its gradients."""
+    import torch
+    loss_mod = sys.modules["scmiac.modeling.loss"]
+    rng = np.random.default_rng(606)
+    f6 = {}
+    for tag, (B, d, T) in {"a": (50, 30, 0.5), "b": (256, 30, 0.5), "c": (300, 50, 0.1), "d": (7, 3, 1.0)}.items():
+        base = rng.normal(size=(B, d))
+        zi = (base + 0.5 * rng.normal(size=(B, d))).astype(np.float32) * 3.0
+        zj = (base + 0.5 * rng.normal(size=(B, d))).astype(np.float32)
+        ti = torch.tensor(zi, requires_grad=True)
+        tj = torch.tensor(zj, requires_grad=True)
+        loss = loss_mod.NTXentLoss2(temperature=T)(ti, tj)
+        (loss * 300.0).backward()  # lambda_contra of the training loop (scmiac.py:181, 264)
+        f6[f"{tag}_zi"], f6[f"{tag}_zj"] = zi, zj
+        f6[f"{tag}_T"] = np.float64(T)
+        f6[f"{tag}_loss"] = loss.detach().numpy()
+        f6[f"{tag}_dzi"], f6[f"{tag}_dzj"] = ti.grad.numpy(), tj.grad.numpy()
+    np.savez_compressed(out / "f6_ntxent.npz", **f6)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--out", default=str(ROOT / "tests" / "golden"))
-    ap.add_argument("--only", default="", help="'f5': regenerate only the CCA fixture")
+    ap.add_argument("--only", default="", help="'f5' / 'f6': regenerate only the CCA / the loss fixture")
     args = ap.parse_args()
     out = Path(args.out)
     out.mkdir(parents=True, exist_ok=True)
     ref, scm = load_reference(Path(args.ref))
     if args.only == "f5":
         cca_fixture(ref, out)
+        return
+    if args.only == "f6":
+        ntxent_fixture(out)
         return
 
     # ---- F1: find_mnn on random tables (duplicates inside rows allowed) --------
@@ -289,6 +314,7 @@ def main():
               cca_score=cdf["score"].values.astype(np.float64))
     np.savez_compressed(out / "f4_find_anchor.npz", **f4)
     cca_fixture(ref, out)
+    ntxent_fixture(out)
 
     for f in sorted(out.glob("*.npz")):
         print(f.name, f.stat().st_size)

@@ -291,6 +291,32 @@ def cca(data1, data2, scale1=True, scale2=True, n_components=50, max_cc_cell=200
     return U, V, features
 
 
+# ---------------------------------------------------------------- downstream consumer
+def ntxent2(z_i, z_j, temperature=0.5):
+    """Symmetric NT-Xent loss (modeling/loss.py:108-132) in float64 numpy; returns
+    ``(loss, d loss / d z_i, d loss / d z_j)``."""
+    z_i = np.asarray(z_i, dtype=np.float64)
+    z_j = np.asarray(z_j, dtype=np.float64)
+    B = z_i.shape[0]
+    ni = np.maximum(np.linalg.norm(z_i, axis=1, keepdims=True), 1e-12)
+    nj = np.maximum(np.linalg.norm(z_j, axis=1, keepdims=True), 1e-12)
+    a, b = z_i / ni, z_j / nj
+    S = a @ b.T / temperature
+
+    def lse(M, axis):
+        m = M.max(axis=axis, keepdims=True)
+        return np.squeeze(m, axis) + np.log(np.exp(M - m).sum(axis=axis))
+
+    lr, lc = lse(S, 1), lse(S, 0)
+    diag = np.diag(S)
+    loss = 0.5 * ((lr - diag).mean() + (lc - diag).mean())
+    dS = 0.5 / B * (np.exp(S - lr[:, None]) + np.exp(S - lc[None, :]) - 2.0 * np.eye(B))
+    ga, gb = dS @ b / temperature, dS.T @ a / temperature
+    dzi = (ga - a * (a * ga).sum(1, keepdims=True)) / ni
+    dzj = (gb - b * (b * gb).sum(1, keepdims=True)) / nj
+    return loss, dzi, dzj
+
+
 # ------------------------------------------------------------ pairwise orchestration
 def l2_normalize_rows(X):
     """sklearn.preprocessing.normalize(X, axis=1) for dense input

@@ -42,6 +42,9 @@ _SIGNATURES = {
     "scmiac_knn_grid_plan": ([_i64, _i64, _i32, _i32, _i32, _c.POINTER(_i64)], _c.c_int),
     "scmiac_knn_set_timing": ([_i32], _c.c_int),
     "scmiac_knn_fused_ms": ([_c.POINTER(_c.c_float), _c.POINTER(_c.c_int)], _c.c_int),
+    "scmiac_ntxent2_parts": ([_i64], _c.c_int),
+    "scmiac_ntxent2_forward": ([_vp, _vp, _i64, _i32, _c.c_float, _vp, _vp, _vp, _vp], _c.c_int),
+    "scmiac_ntxent2_backward": ([_vp, _vp, _i64, _i32, _c.c_float, _vp, _vp, _vp, _vp, _vp, _vp], _c.c_int),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -275,3 +278,37 @@ def fused_ms():
     cnt = ctypes.c_int(0)
     _check(load_library().scmiac_knn_fused_ms(ctypes.byref(ms), ctypes.byref(cnt)))
     return float(ms.value), int(cnt.value)
+
+
+def ntxent2_forward(zi, zj, temperature):
+    """Symmetric NT-Xent loss of two float32 ``[batch, d]`` device tensors.
+
+    Returns ``(loss_parts, lse_row, lse_col)``: the loss is ``loss_parts.sum()``; the
+    two log-sum-exp vectors are what :func:`ntxent2_backward` needs."""
+    lib = require_gpu()
+    device = zi.device
+    zi, zj = _dev_f32(zi, device), _dev_f32(zj, device)
+    if zi.ndim != 2 or zi.shape != zj.shape:
+        raise ValueError("zi and zj must be 2-D tensors of the same shape")
+    batch, d = zi.shape
+    parts = torch.empty((max(lib.scmiac_ntxent2_parts(batch), 1),), dtype=torch.float32, device=device)
+    lse_row = torch.empty((batch,), dtype=torch.float32, device=device)
+    lse_col = torch.empty((batch,), dtype=torch.float32, device=device)
+    with torch.cuda.device(device):
+        _check(lib.scmiac_ntxent2_forward(_ptr(zi), _ptr(zj), batch, d, float(temperature), _ptr(lse_row),
+                                          _ptr(lse_col), _ptr(parts), _stream()))
+    return parts, lse_row, lse_col
+
+
+def ntxent2_backward(zi, zj, temperature, lse_row, lse_col, grad_out):
+    """Gradients of the loss with respect to ``zi`` and ``zj`` (``grad_out``: one float32 on the device)."""
+    lib = require_gpu()
+    device = zi.device
+    zi, zj = _dev_f32(zi, device), _dev_f32(zj, device)
+    grad_out = _dev_f32(grad_out, device).reshape(1)
+    batch, d = zi.shape
+    dzi, dzj = torch.empty_like(zi), torch.empty_like(zj)
+    with torch.cuda.device(device):
+        _check(lib.scmiac_ntxent2_backward(_ptr(zi), _ptr(zj), batch, d, float(temperature), _ptr(lse_row),
+                                           _ptr(lse_col), _ptr(grad_out), _ptr(dzi), _ptr(dzj), _stream()))
+    return dzi, dzj

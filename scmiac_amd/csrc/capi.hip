@@ -271,4 +271,35 @@ int scmiac_knn_fused_ms(float* total_ms, int* launches) {
     return SCMIAC_OK;
 }
 
+int scmiac_ntxent2_parts(int64_t batch) { return batch > 0 ? ntxent2_blocks((int)batch) : 0; }
+
+static int check_ntxent_args(int64_t batch, int d, float temperature) {
+    if (batch < 1 || batch > (1 << 24)) return fail(SCMIAC_ERR_ARG, "batch=%lld outside 1..2^24", (long long)batch);
+    if (d < 1 || d > 64) return fail(SCMIAC_ERR_ARG, "d=%d outside 1..64", d);
+    if (!(temperature > 0.f)) return fail(SCMIAC_ERR_ARG, "temperature must be positive");
+    return SCMIAC_OK;
+}
+
+int scmiac_ntxent2_forward(const float* zi, const float* zj, int64_t batch, int d, float temperature, float* lse_row,
+                           float* lse_col, float* loss_parts, void* stream_) {
+    if (int rc = check_ntxent_args(batch, d, temperature)) return rc;
+    if (!zi || !zj || !lse_row || !lse_col || !loss_parts) return fail(SCMIAC_ERR_ARG, "NULL device pointer");
+    HIP_TRY(launch_ntxent2_forward(zi, zj, (int)batch, d, temperature, lse_row, lse_col, loss_parts,
+                                   static_cast<hipStream_t>(stream_)),
+            "ntxent2_forward");
+    return SCMIAC_OK;
+}
+
+int scmiac_ntxent2_backward(const float* zi, const float* zj, int64_t batch, int d, float temperature,
+                            const float* lse_row, const float* lse_col, const float* grad_out, float* dzi,
+                            float* dzj, void* stream_) {
+    if (int rc = check_ntxent_args(batch, d, temperature)) return rc;
+    if (!zi || !zj || !lse_row || !lse_col || !grad_out || !dzi || !dzj)
+        return fail(SCMIAC_ERR_ARG, "NULL device pointer");
+    HIP_TRY(launch_ntxent2_backward(zi, zj, (int)batch, d, temperature, lse_row, lse_col, grad_out, dzi, dzj,
+                                    static_cast<hipStream_t>(stream_)),
+            "ntxent2_backward");
+    return SCMIAC_OK;
+}
+
 }  // extern "C"

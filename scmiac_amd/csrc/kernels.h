@@ -80,4 +80,12 @@ hipError_t launch_anchor_filter(const long long* pairs, const long long* n_pairs
                                 long long* out_index, long long* counts, double* all_score, void* ws,
                                 hipStream_t stream);
 
+// contrastive_kernels.hip
+int ntxent2_blocks(int B);
+hipError_t launch_ntxent2_forward(const float* zi, const float* zj, int B, int d, float temperature, float* lse_row,
+                                  float* lse_col, float* loss_parts, hipStream_t stream);
+hipError_t launch_ntxent2_backward(const float* zi, const float* zj, int B, int d, float temperature,
+                                   const float* lse_row, const float* lse_col, const float* grad_out, float* dzi,
+                                   float* dzj, hipStream_t stream);
+
 }  // namespace scmiac

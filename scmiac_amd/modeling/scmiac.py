@@ -1,6 +1,6 @@
 """``find_anchors`` with the reference signature (``scmiac/modeling/scmiac.py:14-111``).
 
-The feature selection and CCA run on the host as in the reference; the k-NN
+The feature selection runs on the host as in the reference; the CCA, the k-NN
 tables, mutual-nearest-neighbour pairs, shared-neighbour counts, score threshold
 and cell-type filter run on the GPU.  The returned frame has the reference's
 columns, dtypes, row order and index labels.

@@ -137,3 +137,14 @@ def test_matrix_free_cca_host_logic(golden, tag, monkeypatch):
     np.testing.assert_allclose(V, f[f"{tag}_V"], rtol=0, atol=1e-10)
     if kf:
         np.testing.assert_array_equal(hdf, f[f"{tag}_hdf"])
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_ntxent_restatement_matches_reference(golden, tag):
+    """The float64 restatement of the symmetric NT-Xent loss against the reference's
+    module (fixture F6: float32 on the CPU, gradients of 300 x loss)."""
+    f = golden["f6_ntxent"]
+    loss, dzi, dzj = oracle.ntxent2(f[f"{tag}_zi"], f[f"{tag}_zj"], float(f[f"{tag}_T"]))
+    np.testing.assert_allclose(loss, float(f[f"{tag}_loss"]), rtol=1e-6)
+    for got, want in ((300 * dzi, f[f"{tag}_dzi"]), (300 * dzj, f[f"{tag}_dzj"])):
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=2e-6 * float(np.abs(want).max()))
