@@ -186,6 +186,24 @@ SCMIAC_API int scmiac_knn_set_timing(int enabled);
 SCMIAC_API int scmiac_knn_fused_ms(float *total_ms, int *launches);
 
 /*
+ * Closer-than-the-match counts, the integer behind FOSCTTM: replaces the dense
+ * distance matrix and the `d < diag` comparison of foscttm
+ * (scmiac/evaluation/benchmark.py:99-106) and of partially_matched_foscttm
+ * (benchmark.py:148-157).  For query row i with true match r[match[i]] (match == NULL:
+ * row i of r, which then needs m == n):
+ *     counts[i] = #{ j : D(q_i, r_j) < D(q_i, r_match(i)) },   uint32 [n]
+ * with D the float32 direct-difference squared distance of the k-NN entry points
+ * (strict comparison, like the reference's `<`).  The N x M matrix is never formed.
+ * FOSCTTM of row i is counts[i] / m.  *status (int32, device) becomes 1 if a match
+ * index lies outside [0, m).  Workspace: scmiac_closer_count_workspace_size bytes.
+ * Same limits as scmiac_knn_search (d <= 128, finite inputs).
+ */
+SCMIAC_API int scmiac_closer_count_workspace_size(int64_t n, int64_t m, int d, size_t *bytes);
+SCMIAC_API int scmiac_closer_count(const float *q, int64_t n, const float *r, int64_t m, int d,
+                                   const int32_t *match, uint32_t *counts, int32_t *status, void *workspace,
+                                   size_t workspace_bytes, void *stream);
+
+/*
  * Symmetric NT-Xent loss between the two embeddings of a batch of anchor cells:
  * replaces NTXentLoss2.forward (scmiac/modeling/loss.py:96-133) and its autograd
  * backward, one launch each.  zi, zj: float32 [batch, d] row-major on the device,

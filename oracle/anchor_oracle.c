@@ -187,3 +187,29 @@ ORACLE_API int oracle_snn_score(const int64_t *pairs, int64_t n_anchor, const in
     }
     return 0;
 }
+
+/*
+ * For every row i of Q: how many rows of R are closer to it than R[match[i]]
+ * (match == NULL: R[i]), with the float32 direct-difference squared distance and a
+ * strict comparison.  This is the integer behind FOSCTTM
+ * (scmiac/evaluation/benchmark.py:102-106: dist matrix, `d < diag`, mean), taken
+ * with the k-NN path's distance arithmetic instead of the reference's
+ * x_sq + y_sq - 2 x.y^T, whose rounding depends on the BLAS in use.
+ * Returns 1 if a match index is out of range.
+ */
+ORACLE_API int oracle_closer_count(const float *Q, int64_t n, const float *R, int64_t m, int d,
+                                   const int32_t *match, uint32_t *counts) {
+    int bad = 0;
+#pragma omp parallel for schedule(dynamic, 16) reduction(| : bad)
+    for (int64_t i = 0; i < n; ++i) {
+        int64_t mi = match ? (int64_t)match[i] : i;
+        counts[i] = 0;
+        if (mi < 0 || mi >= m) { bad |= 1; continue; }
+        const float *q = Q + i * (int64_t)d;
+        float dm = dist2_f32(q, R + mi * (int64_t)d, d);
+        uint32_t c = 0;
+        for (int64_t j = 0; j < m; ++j) c += dist2_f32(q, R + j * (int64_t)d, d) < dm;
+        counts[i] = c;
+    }
+    return bad;
+}

@@ -152,6 +152,47 @@ def ntxent_fixture(out):
     np.savez_compressed(out / "f6_ntxent.npz", **f6)
 
 
+def evaluation_fixture(ref_root, out):
+    """F7: the reference's distance-based metrics (evaluation/benchmark.py, loaded by
+    path; it needs only numpy / scipy / scikit-learn / torch) on small embeddings."""
+    spec = importlib.util.spec_from_file_location("scmiac_eval_benchmark",
+                                                  str(ref_root / "scmiac" / "evaluation" / "benchmark.py"))
+    bm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bm)
+    rng = np.random.default_rng(707)
+    f7 = {}
+    n, d = 600, 30
+    centres = rng.normal(size=(8, d)) * 2.0
+    lab = rng.integers(0, 8, n)
+    x = (centres[lab] + rng.normal(size=(n, d))).astype(np.float32)
+    y = (x + 0.9 * rng.normal(size=(n, d))).astype(np.float32)
+    f7["nc_10"] = np.float64(bm.neighbor_conservation(x, y, n_neighbors=10))
+    f7["nc_15_ex1"] = np.float64(bm.neighbor_conservation(x, y, n_neighbors=15, exclude_top=1))
+    for k in (1, 5):
+        res = bm.knn_matching(x, y, k=k)
+        f7[f"match_k{k}"] = np.array([res["rna_to_atac_accuracy"], res["atac_to_rna_accuracy"],
+                                      res["overall_accuracy"]], dtype=np.float64)
+    f7.update(x_clean=x.copy(), y_clean=y.copy())
+    x[7] = x[3]          # duplicated cells: equal distances, decided by the strict "<"
+    y[11] = y[5]
+    y[20] = x[20]        # a perfect match: distance zero
+    fx, fy = bm.foscttm(x, y)
+    f7.update(x=x, y=y, fos_x=fx, fos_y=fy)
+    xu = x / np.linalg.norm(x, axis=1, keepdims=True)
+    yu = y / np.linalg.norm(y, axis=1, keepdims=True)
+    fxu, fyu = bm.foscttm(xu, yu)
+    f7.update(xu=xu, yu=yu, fosu_x=fxu, fosu_y=fyu)
+    # partially matched: x has 500 of the cells, y 450, 380 in common, shuffled
+    names = np.array([f"cell{i:04d}" for i in range(n)])
+    px = rng.permutation(n)[:500]
+    py = np.concatenate([px[:380], np.setdiff1d(np.arange(n), px)[:70]])
+    rng.shuffle(py)
+    (pfx, pfy), _ = quiet(bm.partially_matched_foscttm, x[px].astype(np.float64), y[py].astype(np.float64),
+                          names[px], names[py])
+    f7.update(part_px=px, part_py=py, part_fx=pfx, part_fy=pfy)
+    np.savez_compressed(out / "f7_evaluation.npz", **f7)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -166,6 +207,9 @@ def main():
         return
     if args.only == "f6":
         ntxent_fixture(out)
+        return
+    if args.only == "f7":
+        evaluation_fixture(Path(args.ref), out)
         return
 
     # ---- F1: find_mnn on random tables (duplicates inside rows allowed) --------
@@ -315,6 +359,7 @@ def main():
     np.savez_compressed(out / "f4_find_anchor.npz", **f4)
     cca_fixture(ref, out)
     ntxent_fixture(out)
+    evaluation_fixture(Path(args.ref), out)
 
     for f in sorted(out.glob("*.npz")):
         print(f.name, f.stat().st_size)

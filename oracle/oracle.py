@@ -58,6 +58,9 @@ def _lib():
         lib.oracle_snn_score.argtypes = [i64p, i64, i32p, i32p, i32p, i32p, i64, i64, i64,
                                          ctypes.c_int, i32p]
         lib.oracle_snn_score.restype = ctypes.c_int
+        lib.oracle_closer_count.argtypes = [f32p, i64, f32p, i64, ctypes.c_int, i32p,
+                                            ctypes.POINTER(ctypes.c_uint32)]
+        lib.oracle_closer_count.restype = ctypes.c_int
         _LIB = lib
     return _LIB
 
@@ -289,6 +292,60 @@ def cca(data1, data2, scale1=True, scale2=True, n_components=50, max_cc_cell=200
         right = np.dot(model.components_[keep], tf2).T
         U = np.concatenate([np.dot(tmp, right) for tmp in chunks(data1, scalers[0])], axis=0) / sv
     return U, V, features
+
+
+# ------------------------------------------------------------------------ evaluation
+def closer_count(query, ref, match=None):
+    """``counts[i] = #{j : D(q_i, r_j) < D(q_i, r_match(i))}`` (uint32), float32
+    direct-difference distances, strict comparison."""
+    q = np.ascontiguousarray(np.asarray(query), dtype=np.float32)
+    r = np.ascontiguousarray(np.asarray(ref), dtype=np.float32)
+    n, d = q.shape
+    counts = np.empty(n, dtype=np.uint32)
+    mp = None
+    if match is not None:
+        match = np.ascontiguousarray(np.asarray(match), dtype=np.int32)
+        mp = _p(match, ctypes.c_int32)
+    elif r.shape[0] != n:
+        raise ValueError("Shapes do not match!")
+    if _lib().oracle_closer_count(_p(q, ctypes.c_float), n, _p(r, ctypes.c_float), r.shape[0], d, mp,
+                                  _p(counts, ctypes.c_uint32)):
+        raise IndexError("match index out of bounds")
+    return counts
+
+
+def foscttm(x, y):
+    """Fraction of samples closer than the true match, both directions
+    (evaluation/benchmark.py:75-112), as float32 like the reference's ``.float().mean()``."""
+    x = np.asarray(x)
+    y = np.asarray(y)
+    if x.shape != y.shape:
+        raise ValueError("Shapes do not match!")
+    n = np.float32(x.shape[0])
+    return (closer_count(x, y).astype(np.float32) / n, closer_count(y, x).astype(np.float32) / n)
+
+
+def neighbor_conservation(orig_data, latent_data, n_neighbors=10, exclude_top=0):
+    """Mean Jaccard index of the k-NN sets in the two spaces (evaluation/benchmark.py:35-68),
+    with the exact (distance, index)-ordered search."""
+    k = n_neighbors + exclude_top
+    a = knn(orig_data, orig_data, k)[0][:, exclude_top:]
+    b = knn(latent_data, latent_data, k)[0][:, exclude_top:]
+    scores = [len(set(u) & set(v)) / len(set(u) | set(v)) for u, v in zip(a, b)]
+    return np.mean(scores)
+
+
+def knn_matching(rna_latent, atac_latent, k=1):
+    """Share of cells whose true match is among the k most cosine-similar cells of the
+    other modality (evaluation/benchmark.py:342-374): on unit rows, cosine order is
+    Euclidean order."""
+    a = l2_normalize_rows(rna_latent).astype(np.float32)
+    b = l2_normalize_rows(atac_latent).astype(np.float32)
+    hit_a = (knn(a, b, k)[0] == np.arange(len(a))[:, None]).any(axis=1).sum()
+    hit_b = (knn(b, a, k)[0] == np.arange(len(b))[:, None]).any(axis=1).sum()
+    return {"rna_to_atac_accuracy": np.round(hit_a / len(a), 5),
+            "atac_to_rna_accuracy": np.round(hit_b / len(b), 5),
+            "overall_accuracy": np.round((hit_a + hit_b) / (len(a) + len(b)), 5)}
 
 
 # ---------------------------------------------------------------- downstream consumer

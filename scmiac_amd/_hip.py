@@ -42,6 +42,8 @@ _SIGNATURES = {
     "scmiac_knn_grid_plan": ([_i64, _i64, _i32, _i32, _i32, _c.POINTER(_i64)], _c.c_int),
     "scmiac_knn_set_timing": ([_i32], _c.c_int),
     "scmiac_knn_fused_ms": ([_c.POINTER(_c.c_float), _c.POINTER(_c.c_int)], _c.c_int),
+    "scmiac_closer_count_workspace_size": ([_i64, _i64, _i32, _c.POINTER(_sz)], _c.c_int),
+    "scmiac_closer_count": ([_vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _sz, _vp], _c.c_int),
     "scmiac_ntxent2_parts": ([_i64], _c.c_int),
     "scmiac_ntxent2_forward": ([_vp, _vp, _i64, _i32, _c.c_float, _vp, _vp, _vp, _vp], _c.c_int),
     "scmiac_ntxent2_backward": ([_vp, _vp, _i64, _i32, _c.c_float, _vp, _vp, _vp, _vp, _vp, _vp], _c.c_int),
@@ -312,3 +314,33 @@ def ntxent2_backward(zi, zj, temperature, lse_row, lse_col, grad_out):
         _check(lib.scmiac_ntxent2_backward(_ptr(zi), _ptr(zj), batch, d, float(temperature), _ptr(lse_row),
                                            _ptr(lse_col), _ptr(grad_out), _ptr(dzi), _ptr(dzj), _stream()))
     return dzi, dzj
+
+
+def closer_count(q, r, match=None):
+    """``counts[i] = #{j : D(q_i, r_j) < D(q_i, r_match(i))}`` as an int64 device tensor
+    (``match=None``: row ``i`` of ``r``).  Raises ``IndexError`` for a match index outside ``r``."""
+    lib = require_gpu()
+    device = q.device
+    q, r = _dev_f32(q, device), _dev_f32(r, device)
+    if q.ndim != 2 or r.ndim != 2 or q.shape[1] != r.shape[1]:
+        raise ValueError("q and r must be 2-D with the same number of columns")
+    n, d = q.shape
+    m = r.shape[0]
+    if match is None and n != m:
+        raise ValueError("Shapes do not match!")
+    if match is not None:
+        match = _dev_i32(match, device)
+        if match.shape != (n,):
+            raise ValueError("match needs one entry per query row")
+    counts = torch.zeros((max(n, 1),), dtype=torch.int32, device=device)
+    status = torch.zeros((1,), dtype=torch.int32, device=device)
+    if n:
+        nbytes = ctypes.c_size_t(0)
+        _check(lib.scmiac_closer_count_workspace_size(n, m, d, ctypes.byref(nbytes)))
+        ws = _workspace(nbytes.value, device)
+        with torch.cuda.device(device):
+            _check(lib.scmiac_closer_count(_ptr(q), n, _ptr(r), m, d, _ptr(match), _ptr(counts), _ptr(status),
+                                           _ptr(ws), ws.numel(), _stream()))
+        if int(status.item()):
+            raise IndexError("match index out of bounds")
+    return counts[:n].to(torch.int64)

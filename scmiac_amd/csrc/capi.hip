@@ -271,6 +271,59 @@ int scmiac_knn_fused_ms(float* total_ms, int* launches) {
     return SCMIAC_OK;
 }
 
+// workspace of a count: the k-NN carve-up, with the thresholds and counts in the (unused)
+// shortlist region and the parked references in the pending-candidate region
+static size_t count_pend_offset_total(const KnnGeometry& g, int64_t n, KnnWs* w_out) {
+    KnnWs w = knn_carve(nullptr, n, g);
+    if (w_out) *w_out = w;
+    return up256(w.total) + up256(closer_count_pend_bytes(g));
+}
+
+int scmiac_closer_count_workspace_size(int64_t n, int64_t m, int d, size_t* bytes) {
+    if (!bytes) return fail(SCMIAC_ERR_ARG, "bytes is NULL");
+    int rc = check_knn_args(n, m, d, 1);
+    if (rc) return rc;
+    KnnGeometry g = knn_geometry(n, m, d, 30, 0);
+    if (g.D2 < 0) return fail(SCMIAC_ERR_ARG, "unsupported feature dimension %d", d);
+    *bytes = count_pend_offset_total(g, n, nullptr);
+    return SCMIAC_OK;
+}
+
+int scmiac_closer_count(const float* q, int64_t n, const float* r, int64_t m, int d, const int32_t* match,
+                        uint32_t* counts, int32_t* status, void* workspace, size_t workspace_bytes, void* stream_) {
+    int rc = check_knn_args(n, m, d, 1);
+    if (rc) return rc;
+    if (!match && n != m) return fail(SCMIAC_ERR_ARG, "without a match array the two sides need equal row counts");
+    if (n == 0) return SCMIAC_OK;
+    if (m == 0) return fail(SCMIAC_ERR_ARG, "no reference rows");
+    if (!q || !r || !counts || !status || !workspace) return fail(SCMIAC_ERR_ARG, "NULL device pointer");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    KnnGeometry g = knn_geometry(n, m, d, 30, 0);
+    if (g.D2 < 0) return fail(SCMIAC_ERR_ARG, "unsupported feature dimension %d", d);
+    KnnWs w0;
+    size_t total = count_pend_offset_total(g, n, &w0);
+    if (total > workspace_bytes)
+        return fail(SCMIAC_ERR_WORKSPACE, "workspace holds %zu bytes, %zu needed", workspace_bytes, total);
+    KnnWs w = knn_carve(workspace, n, g);
+    unsigned* pend = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + up256(w.total));
+    float* lo = reinterpret_cast<float*>(w.lists);
+    float* hi = lo + g.n_pad;
+    float* dmatch = hi + g.n_pad;
+    unsigned* cnt = reinterpret_cast<unsigned*>(dmatch + g.n_pad);
+    if ((size_t)g.n_pad * 16 > sizeof(unsigned long long) * (size_t)g.list_rows * 64)
+        return fail(SCMIAC_ERR_WORKSPACE, "internal: threshold region too small");
+    HIP_TRY(hipMemsetAsync(w.maxnorm, 0, 256, stream), "memset maxnorm");
+    HIP_TRY(hipMemsetAsync(status, 0, sizeof(int32_t), stream), "memset status");
+    HIP_TRY(launch_pack(q, n, d, g, -2.0f, w.qp, g.rowf, nullptr, g.n_pad, w.maxnorm, stream), "pack queries");
+    HIP_TRY(launch_pack(r, m, d, g, 1.0f, w.rp, g.ls, w.rnorm, g.m_pad, w.maxnorm, stream), "pack references");
+    HIP_TRY(launch_closer_count(g, q, r, match, d, n, m, w.qp, w.rp, w.rnorm, w.maxnorm, lo, hi, dmatch, cnt, pend,
+                                status, stream),
+            "closer count");
+    HIP_TRY(hipMemcpyAsync(counts, cnt, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, stream),
+            "copy counts");
+    return SCMIAC_OK;
+}
+
 int scmiac_ntxent2_parts(int64_t batch) { return batch > 0 ? ntxent2_blocks((int)batch) : 0; }
 
 static int check_ntxent_args(int64_t batch, int d, float temperature) {

@@ -80,6 +80,13 @@ hipError_t launch_anchor_filter(const long long* pairs, const long long* n_pairs
                                 long long* out_index, long long* counts, double* all_score, void* ws,
                                 hipStream_t stream);
 
+// count_kernels.hip: references closer than the true match, per query row
+size_t closer_count_pend_bytes(const KnnGeometry& g);
+hipError_t launch_closer_count(const KnnGeometry& g, const float* Q, const float* R, const int* match, int d,
+                               long long n, long long m, const float* Qp, const float* Rp, const float* rnorm,
+                               const unsigned* maxnorm_bits, float* lo, float* hi, float* dmatch, unsigned* counts,
+                               unsigned* pend, int* status, hipStream_t stream);
+
 // contrastive_kernels.hip
 int ntxent2_blocks(int B);
 hipError_t launch_ntxent2_forward(const float* zi, const float* zj, int B, int d, float temperature, float* lse_row,

@@ -148,3 +148,23 @@ def test_ntxent_restatement_matches_reference(golden, tag):
     np.testing.assert_allclose(loss, float(f[f"{tag}_loss"]), rtol=1e-6)
     for got, want in ((300 * dzi, f[f"{tag}_dzi"]), (300 * dzj, f[f"{tag}_dzj"])):
         np.testing.assert_allclose(got, want, rtol=1e-4, atol=2e-6 * float(np.abs(want).max()))
+
+
+def test_evaluation_restatements_match_reference(golden):
+    """FOSCTTM (both directions, raw and unit rows, partially matched), neighbour
+    conservation and k-NN matching of the oracle against the reference's own
+    evaluation/benchmark.py outputs (fixture F7)."""
+    f = golden["f7_evaluation"]
+    for a, b, wa, wb in (("x", "y", "fos_x", "fos_y"), ("xu", "yu", "fosu_x", "fosu_y")):
+        fx, fy = oracle.foscttm(f[a], f[b])
+        np.testing.assert_array_equal(fx, f[wa])
+        np.testing.assert_array_equal(fy, f[wb])
+    x, y = f["x_clean"], f["y_clean"]
+    assert oracle.neighbor_conservation(x, y, 10) == pytest.approx(float(f["nc_10"]), abs=1e-12)
+    assert oracle.neighbor_conservation(x, y, 15, 1) == pytest.approx(float(f["nc_15_ex1"]), abs=1e-12)
+    for k in (1, 5):
+        res = oracle.knn_matching(x, y, k)
+        np.testing.assert_array_equal(
+            [res["rna_to_atac_accuracy"], res["atac_to_rna_accuracy"], res["overall_accuracy"]], f[f"match_k{k}"])
+    with pytest.raises(IndexError):
+        oracle.closer_count(x[:4], y[:4], [0, 1, 2, 4])
