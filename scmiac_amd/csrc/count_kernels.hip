@@ -58,19 +58,17 @@ __global__ __launch_bounds__(256) void closer_thresholds_kernel(
     dmatch[q] = D;
 }
 
-// what the stage loop does with a finished subtile: count the scores below `lo` (a compare
-// and an add-with-carry per register) and look for scores in [lo, hi) (a second compare;
-// the rest is scalar)
+// what the stage loop does with a finished subtile: nothing, unless some score lies below
+// `hi` (smallest of the lane's 16 scores as a depth-3 tree, as in the k-NN search)
 #define SCMIAC_TEST_PREV(PRV_)                                                                      \
     do {                                                                                            \
-        u64 band_any_ = 0ull;                                                                       \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                            \
-            const float s_ = accs[PRV_][r];                                                         \
-            const bool c_ = s_ < lo;                                                                \
-            cnt += c_ ? 1u : 0u;                                                                    \
-            band_any_ |= __ballot(!c_ && s_ < hi);                                                  \
-        }                                                                                           \
-        if (__builtin_expect(band_any_ != 0ull, 0)) band_slow(accs[PRV_], ref0s[PRV_]);             \
+        const float m0_ = min3_after_mfma(accs[PRV_][0], accs[PRV_][1], accs[PRV_][2]);             \
+        const float m1_ = min3_raw_after(accs[PRV_][3], accs[PRV_][4], accs[PRV_][5], m0_);         \
+        const float m2_ = min3_raw_after(accs[PRV_][6], accs[PRV_][7], accs[PRV_][8], m0_);         \
+        const float m3_ = min3_raw_after(accs[PRV_][9], accs[PRV_][10], accs[PRV_][11], m0_);       \
+        const float m4_ = min3_raw_after(accs[PRV_][12], accs[PRV_][13], accs[PRV_][14], m0_);      \
+        const float mn_ = min2_raw(min3_raw(m0_, m1_, m2_), min3_raw(m3_, m4_, accs[PRV_][15]));    \
+        if (__any(mn_ < hi)) count_slow(accs[PRV_], ref0s[PRV_]);                                   \
     } while (0)
 
 template <int D2, int NW_, int RT_>
@@ -154,19 +152,30 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
         }
         pcnt = 0u;
     };
-    // some score of the subtile lies in [lo, hi): park those references
-    auto band_slow = [&](const f32x16& acc, unsigned ref0_wave) __attribute__((always_inline)) {
+    // some score of the subtile lies below `hi`: count the ones below `lo` (a compare into a
+    // scalar mask and an add-with-carry per register) and park the references whose score
+    // falls in [lo, hi)
+    auto count_slow = [&](const f32x16& acc, unsigned ref0_wave) __attribute__((always_inline)) {
         f32x16 sc = acc;
         asm volatile("" : "+v"(sc));  // keeps this path's arithmetic behind the branch that guards it
-        if (__any(pcnt > (unsigned)(kPendCap - 16))) settle();
-        const unsigned ref0 = ref0_wave + 4u * (unsigned)hh;
+        u64 band = 0ull;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const bool b = !(sc[r] < lo) && sc[r] < hi;
-            if (__any(b)) {
-                if (b) {
-                    pend_l[pcnt] = ref0 + (unsigned)((r & 3) + 8 * (r >> 2));
-                    ++pcnt;
+            const u64 ml = __ballot(sc[r] < lo), mh = __ballot(sc[r] < hi);
+            cnt += (sc[r] < lo) ? 1u : 0u;
+            band |= mh & ~ml;
+        }
+        if (__builtin_expect(band != 0ull, 0)) {
+            if (__any(pcnt > (unsigned)(kPendCap - 16))) settle();
+            const unsigned ref0 = ref0_wave + 4u * (unsigned)hh;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const bool b = sc[r] >= lo && sc[r] < hi;
+                if (__any(b)) {
+                    if (b) {
+                        pend_l[pcnt] = ref0 + (unsigned)((r & 3) + 8 * (r >> 2));
+                        ++pcnt;
+                    }
                 }
             }
         }
@@ -211,7 +220,7 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    if (T > 0) SCMIAC_TEST_PREV(1);  // the last subtile
+    if (T > 0) count_slow(accs[1], ref0s[1]);  // the last subtile
     settle();
     if (cnt) atomicAdd(counts + q0 + j, cnt);
 }
