@@ -314,6 +314,12 @@ def main():
     for nm, g in zip(("G11", "G12", "G21", "G22"), integ.mutual_knn[(0, 1)]):
         f4[f"pre_{nm}"] = np.asarray(g, dtype=np.int32)
 
+    # nearest anchors of every query cell with 100 neighbours (anchors.py:1189-1241)
+    (anc, G, D, cum), _ = quiet(integ.find_nearest_anchor, [U, V], V, [0], [1], key_correct="lat", npc=30,
+                                k_weight=100)
+    f4.update(nearest_anchor=np.asarray(anc, dtype=np.int64), nearest_G=np.asarray(G, dtype=np.int32),
+              nearest_D=np.asarray(D, dtype=np.float64), nearest_cum=np.asarray(cum, dtype=np.int64))
+
     # label join + filters exactly as scmiac.find_anchors does them (scmiac.py:90-99):
     # drive the reference function itself with the two heavy upstream steps replaced
     class _Integ(ref.SeuratIntegration):

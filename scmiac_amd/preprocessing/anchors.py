@@ -49,8 +49,8 @@ class NNDescent:
     ``pynndescent.NNDescent`` (call sites anchors.py:546-565, 616-624, 732-740):
     ``NNDescent(data, metric, n_neighbors, ...)``, ``.neighbor_graph`` and
     ``.query(q, k)``, each returning ``(int32 indices, float32 distances)`` with
-    rows sorted by ascending distance (ties by index).  Neighbour counts above
-    64 are not supported."""
+    rows sorted by ascending distance (ties by index).  More than 64 neighbours
+    are served by merging group-wise searches (:mod:`scmiac_amd.wide_knn`)."""
 
     def __init__(self, data, metric="euclidean", n_neighbors=30, random_state=None,
                  parallel_batch_queries=False, n_jobs=None, **kwargs):
@@ -64,14 +64,20 @@ class NNDescent:
     def neighbor_graph(self):
         if self._graph is None:
             k = min(self.n_neighbors, self._data.shape[0])
-            st = _hip.knn_search(self._data, self._data, k)
-            self._graph = (st.idx.cpu().numpy(), st.dist.cpu().numpy())
+            self._graph = self._search(self._data, k)
         return self._graph
+
+    def _search(self, q, k):
+        if k > _hip.KNN_MAX_K:
+            from ..wide_knn import knn_search_wide
+            idx, _, dist = knn_search_wide(q, self._data, k)
+            return idx.cpu().numpy(), dist.cpu().numpy()
+        st = _hip.knn_search(q, self._data, k)
+        return st.idx.cpu().numpy(), st.dist.cpu().numpy()
 
     def query(self, query_data, k=10, epsilon=0.1):
         q = query_data if isinstance(query_data, torch.Tensor) else _to_device_f32(query_data)
-        st = _hip.knn_search(q, self._data, int(k))
-        return st.idx.cpu().numpy(), st.dist.cpu().numpy()
+        return self._search(q, int(k))
 
 
 # ------------------------------------------------------------------- hot path
@@ -150,7 +156,7 @@ def score_anchor(anchor, G11, G12, G21, G22, k_score=30, Gp1=None, Gp2=None, k_l
 def filter_anchor(anchor, adata_ref=None, adata_qry=None, scale_ref=False, scale_qry=False,
                   high_dim_feature=None, k_filter=200, random_state=0, n_jobs=-1):
     """Keep anchors that are still neighbours in the high-loading feature space
-    (anchors.py:584-628).  ``k_filter`` is limited to 64 here."""
+    (anchors.py:584-628).  Up to 128 features."""
     from scipy.sparse import issparse
     from scipy.stats import zscore
     from sklearn.preprocessing import normalize
@@ -397,6 +403,54 @@ class SeuratIntegration:
         self.U = U
         self.V = V
         return anchor_df
+
+    def find_nearest_anchor(self, data, data_qry, ref, qry, key_correct="X_pca", npc=30, k_weight=100, sd=1,
+                            random_state=0):
+        """For every query cell its ``k_weight`` nearest anchors (among the query-side anchor
+        cells) and their Gaussian-kernel weights (anchors.py:1189-1241).  Returns
+        ``(anchor, G, D, cum_qry)`` like the reference."""
+        print("Initialize")
+        cum_ref, cum_qry = [0], [0]
+        for xx in ref:
+            cum_ref.append(cum_ref[-1] + data[xx].shape[0])
+        for xx in qry:
+            cum_qry.append(cum_qry[-1] + data[xx].shape[0])
+
+        frames = []
+        for i, xx in enumerate(ref):
+            for jj, yy in enumerate(qry):
+                if xx < yy:
+                    tmp = self.anchor[(xx, yy)].copy()
+                else:  # stored the other way round: swap the two index columns
+                    tmp = self.anchor[(yy, xx)].copy()
+                    tmp[["x1", "x2"]] = tmp[["x2", "x1"]]
+                tmp["x1"] += cum_ref[i]
+                tmp["x2"] += cum_qry[jj]
+                frames.append(tmp)
+        table = pd.concat(frames)
+        score = table["score"].values
+        anchor = table[["x1", "x2"]].values
+
+        if key_correct == "X":
+            from sklearn.decomposition import PCA
+            reduce_qry = PCA(n_components=npc, svd_solver="arpack", random_state=random_state).fit_transform(data_qry)
+        else:
+            reduce_qry = data_qry[:, :npc]
+
+        print("Find nearest anchors", end=". ")
+        index = NNDescent(reduce_qry[anchor[:, 1]], metric="euclidean", n_neighbors=k_weight,
+                          random_state=random_state)
+        k_weight = max(5, min(k_weight, anchor.shape[0] - 5))
+        print("k_weight: ", k_weight, end="\n")
+        G, D = index.query(reduce_qry, k=k_weight)
+
+        print("Normalize graph")
+        cell_filter = D[:, -1] == 0
+        D = (1 - D / D[:, -1][:, None]) * score[G]
+        D[cell_filter] = score[G[cell_filter]]
+        D = 1 - np.exp(-D * (sd ** 2) / 4)
+        D = D / (np.sum(D, axis=1) + 1e-6)[:, None]
+        return anchor, G, D, cum_qry
 
     def find_anchor(self, adata_list, adata_names=None, k_local=None, key_local="X_pca", key_anchor="X",
                     dim_red="pca", svd_algorithm="randomized", scale1=True, scale2=True, scale_list=None,

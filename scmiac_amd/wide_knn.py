@@ -1,0 +1,68 @@
+"""Exact k-NN for more than 64 neighbours per row, composed from 64-neighbour searches.
+
+``filter_anchor`` and ``find_nearest_anchor`` of the reference ask their index for 200 and
+100 neighbours (``scmiac/preprocessing/anchors.py:616-624, 1222-1233``); the fused kernel
+keeps 64 per row.  The reference rows are dealt round-robin into ``G`` groups, every group
+is searched for its 64 nearest rows, and the group results are merged by ``(distance,
+index)``.  The merge is exact for a query row if no group's list is cut short: every row a
+group did not list comes after that group's 64th key, so the merged top-k is final when
+each full group list ends at or after the k-th merged key.  Rows where that fails (more than
+64 of the k nearest fell into one group) are searched again with twice as many groups;
+groups of at most 64 rows are always complete, so this ends.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import _hip
+
+_SENTINEL = torch.iinfo(torch.int64).max
+
+
+def _group_keys(q, r_group, g, n_groups):
+    """int64 keys (float32 distance bits << 32 | global row) of q's 64 nearest rows in one group."""
+    kk = min(_hip.KNN_MAX_K, r_group.shape[0])
+    st = _hip.knn_search(q, r_group, kk)
+    rows = st.idx.to(torch.int64) * n_groups + g
+    keys = (st.dist2.view(torch.int32).to(torch.int64) << 32) | rows
+    keys = torch.where(st.idx >= 0, keys, torch.full_like(keys, _SENTINEL))
+    if kk < _hip.KNN_MAX_K:  # a short group is listed completely: pad with "nothing further"
+        pad = torch.full((q.shape[0], _hip.KNN_MAX_K - kk), _SENTINEL, dtype=torch.int64, device=q.device)
+        keys = torch.cat([keys, pad], dim=1)
+    return keys
+
+
+def knn_search_wide(q, r, k, *, n_groups=None, query_chunk=32768):
+    """``(idx int32 [n, k], dist2 float32 [n, k], dist float32 [n, k])`` of the k nearest rows
+    of ``r`` for every row of ``q``, ordered by ``(distance, index)``; any ``k <= len(r)``."""
+    _hip.require_gpu()
+    device = q.device
+    n, m = q.shape[0], r.shape[0]
+    if k > m:
+        raise ValueError(f"k={k} exceeds the number of reference rows ({m})")
+    if n_groups is None:
+        n_groups = max(2, 4 * math.ceil(k / _hip.KNN_MAX_K))
+    n_groups = min(n_groups, m)
+    groups = [r[g::n_groups].contiguous() for g in range(n_groups)]
+    idx = torch.empty((n, k), dtype=torch.int32, device=device)
+    d2 = torch.empty((n, k), dtype=torch.float32, device=device)
+    for c0 in range(0, n, query_chunk):
+        qc = q[c0:c0 + query_chunk]
+        keys = torch.cat([_group_keys(qc, rg, g, n_groups) for g, rg in enumerate(groups)], dim=1)
+        top = torch.sort(keys, dim=1).values[:, :k]
+        kth = top[:, k - 1:k]
+        last = keys[:, _hip.KNN_MAX_K - 1::_hip.KNN_MAX_K]     # 64th key of every group
+        cut_short = ((last != _SENTINEL) & (last < kth)).any(dim=1)
+        idx[c0:c0 + qc.shape[0]] = (top & 0xFFFFFFFF).to(torch.int32)
+        d2[c0:c0 + qc.shape[0]] = (top >> 32).to(torch.int32).view(torch.float32)
+        bad = torch.nonzero(cut_short).flatten()
+        if bad.numel():
+            if max(g.shape[0] for g in groups) <= _hip.KNN_MAX_K:
+                raise AssertionError("complete group lists cannot be cut short")
+            i2, d22, _ = knn_search_wide(qc[bad], r, k, n_groups=2 * n_groups, query_chunk=query_chunk)
+            idx[c0 + bad] = i2
+            d2[c0 + bad] = d22
+    dist = d2.to(torch.float64).sqrt().to(torch.float32)
+    return idx, d2, dist

@@ -238,6 +238,19 @@ def test_find_anchor_precomputed_golden(golden, capsys):
     assert "Find Anchors using k=30" in capsys.readouterr().out
 
 
+def test_find_nearest_anchor_golden(golden):
+    """100 nearest anchors per query cell and their weights (anchors.py:1189-1241) against
+    the reference's own method run on the exact stand-in index."""
+    f = golden["f4_find_anchor"]
+    integ = _run_precomputed(f)
+    anchor, G, D, cum = integ.find_nearest_anchor([f["pre_U"], f["pre_V"]], f["pre_V"], [0], [1],
+                                                  key_correct="lat", npc=30, k_weight=100)
+    np.testing.assert_array_equal(anchor, f["nearest_anchor"])
+    np.testing.assert_array_equal(G, f["nearest_G"])
+    np.testing.assert_array_equal(D, f["nearest_D"])   # float64 arithmetic on bit-equal float32 distances
+    assert list(cum) == list(f["nearest_cum"])
+
+
 @pytest.mark.parametrize("ct_filter,tag", [(True, "filt"), (False, "nofilt")])
 def test_label_filter_and_csv_golden(golden, ct_filter, tag):
     f = golden["f4_find_anchor"]

@@ -1,0 +1,53 @@
+"""More than 64 neighbours per row (the counts ``filter_anchor`` and ``find_nearest_anchor``
+ask for, anchors.py:616-624, 1222-1233): merged group searches against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle
+from scmiac_amd.preprocessing import anchors as A
+from scmiac_amd.wide_knn import knn_search_wide
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(q, r, k, **kw):
+    idx_o, d2_o = oracle.knn_dist2(q, r, k)
+    idx, d2, dist = knn_search_wide(torch.from_numpy(q).cuda(), torch.from_numpy(r).cuda(), k, **kw)
+    np.testing.assert_array_equal(idx.cpu().numpy(), idx_o)
+    np.testing.assert_array_equal(d2.cpu().numpy(), d2_o)
+    np.testing.assert_array_equal(dist.cpu().numpy(), np.sqrt(d2_o.astype(np.float64)).astype(np.float32))
+
+
+@pytest.mark.parametrize("n,m,d,k", [(700, 5000, 30, 100), (300, 9000, 50, 200), (50, 150, 8, 100), (40, 130, 5, 130)])
+def test_wide_knn_matches_oracle(n, m, d, k):
+    rng = np.random.default_rng(m + k)
+    centres = rng.normal(size=(6, d)) * 3
+    r = (centres[np.sort(rng.integers(0, 6, m))] + rng.normal(size=(m, d))).astype(np.float32)  # clustered by row number
+    q = (centres[rng.integers(0, 6, n)] + rng.normal(size=(n, d))).astype(np.float32)
+    r[10:40] = r[50:80]  # duplicated rows: ties go by row number
+    _check(q, r, k)
+
+
+def test_wide_knn_cut_short_groups_are_searched_again():
+    """Two groups of 64 listed rows cannot hold 100 neighbours unless they split 50/50:
+    nearly every row takes the finer regrouping, and the result is still exact."""
+    rng = np.random.default_rng(4)
+    r = rng.normal(size=(4000, 16)).astype(np.float32)
+    q = rng.normal(size=(200, 16)).astype(np.float32)
+    _check(q, r, 100, n_groups=2)
+    with pytest.raises(ValueError):
+        knn_search_wide(torch.from_numpy(q).cuda(), torch.from_numpy(r[:50]).cuda(), 60 + 4)
+
+
+def test_index_object_serves_wide_queries():
+    rng = np.random.default_rng(8)
+    data = rng.normal(size=(3000, 30)).astype(np.float32)
+    qry = rng.normal(size=(500, 30)).astype(np.float32)
+    index = A.NNDescent(data, metric="euclidean", n_neighbors=100, random_state=0)
+    G, D = index.query(qry, k=100)                       # find_nearest_anchor's call (anchors.py:1233)
+    idx_o, d2_o = oracle.knn_dist2(qry, data, 100)
+    np.testing.assert_array_equal(G, idx_o)
+    assert G.dtype == np.int32 and D.dtype == np.float32 and D.shape == (500, 100)
+    graph = index.neighbor_graph[0]
+    np.testing.assert_array_equal(graph, oracle.knn_dist2(data, data, 100)[0])
