@@ -138,3 +138,31 @@ def find_neighbor_sharded(cc1, cc2, k, *, group=None, backend=_hip):
     unc = tuple(int(s.n_uncertified.item()) for s in (s11, s12, s21, s22))
     return NeighborTables(G11=g11[:, 1:kk].contiguous(), G12=g12, G21=g21, G22=g22[:, 1:kk].contiguous(),
                           uncertified=unc)
+
+
+def closer_count_sharded(q, r, *, match=None, group=None, backend=_hip):
+    """``closer_count`` (the integer behind FOSCTTM, ``evaluation/benchmark.py:99-106``) with
+    the query rows sharded over the ranks and the references replicated: no collective while
+    counting, one all-gather of the counts.  Every rank passes the full ``q`` / ``r`` /
+    ``match`` and receives all counts (int64 ``[n]``)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    n = q.shape[0]
+    lo, hi = shard_bounds(n, world, rank)
+    if match is None:
+        if r.shape[0] != n:
+            raise ValueError("Shapes do not match!")
+        match = torch.arange(n, dtype=torch.int32, device=q.device)
+    local = backend.closer_count(q[lo:hi], r, match=match[lo:hi])
+    return gather_rows(local.reshape(-1, 1), n, group).reshape(-1)
+
+
+def foscttm_sharded(x, y, *, group=None, backend=_hip):
+    """Both directions of FOSCTTM over the ranks of ``group``: float32 numpy arrays
+    ``(foscttm_x, foscttm_y)`` like the reference's (the division runs on the host)."""
+    import numpy as np
+
+    n = np.float32(x.shape[0])
+    fx = closer_count_sharded(x, y, group=group, backend=backend).cpu().numpy().astype(np.float32) / n
+    fy = closer_count_sharded(y, x, group=group, backend=backend).cpu().numpy().astype(np.float32) / n
+    return fx, fy

@@ -76,6 +76,14 @@ class OracleBackend:
         return state
 
 
+    def closer_count(self, q, r, match=None):
+        if q.shape[0] == 0:
+            return torch.zeros(0, dtype=torch.int64)
+        c = oracle.closer_count(np.ascontiguousarray(q.numpy()), np.ascontiguousarray(r.numpy()),
+                                None if match is None else match.numpy())
+        return torch.from_numpy(c.astype(np.int64))
+
+
 def mixture(seed, n, d):
     rng = np.random.default_rng(seed)
     centres = np.random.default_rng(77).normal(scale=3.0, size=(6, d))
@@ -121,6 +129,14 @@ def main():
     t = sharded.find_neighbor_sharded(torch.from_numpy(U), torch.from_numpy(V), 12, backend=OracleBackend())
     for got, want in zip(t.numpy(), oracle.find_neighbor(U, V, 12)):
         np.testing.assert_array_equal(got, want)
+
+    # --- closer-than-match counts, query rows sharded (ragged last shard)
+    X = mixture(5, 203, d)
+    Y = (X + np.random.default_rng(6).normal(size=X.shape)).astype(np.float32)
+    fx, fy = sharded.foscttm_sharded(torch.from_numpy(X), torch.from_numpy(Y), backend=OracleBackend())
+    want_x, want_y = oracle.foscttm(X, Y)
+    np.testing.assert_array_equal(fx, want_x)
+    np.testing.assert_array_equal(fy, want_y)
 
     dist.barrier()
     dist.destroy_process_group()

@@ -397,6 +397,11 @@ def test_ring_search_unit_norm_d64_single_rank(tmp_path):
         b = anchor_search.find_neighbor_device(U, V, 30)
         for x, y in zip((a.G11, a.G12, a.G21, a.G22), (b.G11, b.G12, b.G21, b.G22)):
             assert torch.equal(x, y)
+        # closer-than-match counts through the sharded driver == the oracle's
+        fx, fy = sharded.foscttm_sharded(U, _dev(_mixture(75, 700, 64, unit=True)))
+        want_x, want_y = oracle.foscttm(U.cpu().numpy(), _mixture(75, 700, 64, unit=True))
+        np.testing.assert_array_equal(fx, want_x)
+        np.testing.assert_array_equal(fy, want_y)
     finally:
         dist.destroy_process_group()
     idx_o, d2_o = oracle.knn_dist2(Q, R, 30)
