@@ -52,6 +52,8 @@ WORKLOADS = {
     # a wide embedding (tuning aid for the d > 64 kernel variants)
     "wide": (200_000, 500_000, 100, 100, (7000, 7001, 7002)),
     "wide128": (200_000, 500_000, 128, 100, (7100, 7101, 7102)),
+    "wide200": (200_000, 500_000, 200, 100, (7200, 7201, 7202)),
+    "wide256": (200_000, 500_000, 256, 100, (7300, 7301, 7302)),
 }
 UNIT_NORM = {"c5shard"}
 

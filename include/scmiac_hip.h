@@ -33,7 +33,7 @@ extern "C" {
 #define SCMIAC_ERR_HIP 3       /* a HIP runtime call failed */
 
 #define SCMIAC_KNN_MAX_K 64   /* neighbours per row one search can return */
-#define SCMIAC_KNN_MAX_D 128  /* feature dimension supported by the fused kernel */
+#define SCMIAC_KNN_MAX_D 256  /* feature dimension supported by the fused kernel */
 
 /* Library/ABI version (major*1000 + minor). */
 SCMIAC_API int scmiac_version(void);
@@ -196,7 +196,7 @@ SCMIAC_API int scmiac_knn_fused_ms(float *total_ms, int *launches);
  * (strict comparison, like the reference's `<`).  The N x M matrix is never formed.
  * FOSCTTM of row i is counts[i] / m.  *status (int32, device) becomes 1 if a match
  * index lies outside [0, m).  Workspace: scmiac_closer_count_workspace_size bytes.
- * Same limits as scmiac_knn_search (d <= 128, finite inputs).
+ * Same limits as scmiac_knn_search (d <= 256, finite inputs).
  */
 SCMIAC_API int scmiac_closer_count_workspace_size(int64_t n, int64_t m, int d, size_t *bytes);
 SCMIAC_API int scmiac_closer_count(const float *q, int64_t n, const float *r, int64_t m, int d,

@@ -16,7 +16,7 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("SCMIAC_HIP_LIB", _HERE / "csrc" / "libscmiac_hip.so"))  # override: experiment builds
 
 KNN_MAX_K = 64
-KNN_MAX_D = 128
+KNN_MAX_D = 256
 
 _lib = None
 

@@ -5,7 +5,7 @@
 #include <stdint.h>
 
 #define SCMIAC_KNN_MAX_K_INTERNAL 64
-#define SCMIAC_KNN_MAX_D_INTERNAL 128
+#define SCMIAC_KNN_MAX_D_INTERNAL 256
 
 namespace scmiac {
 

@@ -654,13 +654,14 @@ __global__ __launch_bounds__(EX_NT) void exact_rows_kernel(
 // --------------------------------------------------------------------------------
 // host-side launchers
 // --------------------------------------------------------------------------------
-static const int kD2Sizes[] = {8, 15, 16, 20, 25, 32, 40, 50, 64};
+static const int kD2Sizes[] = {8, 15, 16, 20, 25, 32, 40, 50, 64, 96, 128};
 // compiled (D2, waves per block, reference rows per LDS stage, pending candidates per query,
 // pending candidates in global memory)
 #define SCMIAC_FUSED_VARIANTS(X) \
     X(8, 12, 320, 32, 1) X(15, 12, 320, 32, 1) X(16, 12, 320, 32, 1) X(20, 12, 320, 32, 1) X(25, 12, 320, 32, 1) \
     X(32, 12, 256, 32, 1) \
     X(40, 12, 128, 32, 1) X(50, 12, 128, 32, 1) X(64, 8, 128, 32, 1) \
+    X(96, 8, 64, 32, 1) X(128, 8, 64, 32, 1) \
     X(25, 12, 128, 32, 0) X(25, 12, 128, 32, 1) X(25, 12, 256, 16, 1) X(25, 12, 256, 32, 1)
 
 int knn_pick_d2(int d) {
@@ -689,10 +690,10 @@ static hipError_t launch_fused_t(const float* Qp, const float* Rp, const float* 
 static void fused_variant(int D2, int* nw, int* rt, int* pcap, int* gp) {
     // 12 waves per block (3 per SIMD) wherever the registers allow (up to 100 features), the
     // pending-candidate buffers in global memory and all of the LDS given to two stages as
-    // long as it holds: 320 rows up to 50 features, 256 up to 64, 128 beyond (fewer barriers,
-    // and the waves' uneven candidate work averages out over a longer stage).
+    // long as it holds: 320 rows up to 50 features, 256 up to 64, 128 up to 128, 64 beyond
+    // (fewer barriers, and the waves' uneven candidate work averages out over a longer stage).
     *nw = (D2 <= 50) ? 12 : 8;
-    *rt = (D2 <= 25) ? 320 : (D2 <= 32) ? 256 : 128;
+    *rt = (D2 <= 25) ? 320 : (D2 <= 32) ? 256 : (D2 <= 64) ? 128 : 64;
     *pcap = 32;
     *gp = 1;
     if (const char* v = getenv("SCMIAC_FUSED_VARIANT")) {  // tuning aid: "NWxRTxPCAPxGP", e.g. 12x256x32x1

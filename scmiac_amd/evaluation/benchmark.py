@@ -69,7 +69,7 @@ def _self_knn(data, k):
 
 def neighbor_conservation(orig_data, latent_data, n_neighbors=10, exclude_top=0):
     """Mean Jaccard index between each cell's neighbour set in the original and in the
-    latent space (``benchmark.py:35-68``).  Up to 128 features and 64 neighbours."""
+    latent space (``benchmark.py:35-68``).  Up to 256 features."""
     k = n_neighbors + exclude_top
     a = _self_knn(orig_data, k)[:, exclude_top:]
     b = _self_knn(latent_data, k)[:, exclude_top:]

@@ -156,7 +156,7 @@ def score_anchor(anchor, G11, G12, G21, G22, k_score=30, Gp1=None, Gp2=None, k_l
 def filter_anchor(anchor, adata_ref=None, adata_qry=None, scale_ref=False, scale_qry=False,
                   high_dim_feature=None, k_filter=200, random_state=0, n_jobs=-1):
     """Keep anchors that are still neighbours in the high-loading feature space
-    (anchors.py:584-628).  Up to 128 features."""
+    (anchors.py:584-628).  Up to 256 features."""
     from scipy.sparse import issparse
     from scipy.stats import zscore
     from sklearn.preprocessing import normalize

@@ -51,3 +51,46 @@ def test_index_object_serves_wide_queries():
     assert G.dtype == np.int32 and D.dtype == np.float32 and D.shape == (500, 100)
     graph = index.neighbor_graph[0]
     np.testing.assert_array_equal(graph, oracle.knn_dist2(data, data, 100)[0])
+
+
+@pytest.mark.parametrize("n,m,d,k", [(600, 7000, 129, 30), (500, 6000, 192, 31), (400, 5000, 200, 30), (300, 4000, 256, 64)])
+def test_wide_feature_rows_match_oracle(n, m, d, k):
+    """129..256 features per row (8 waves per block, 64-row stages)."""
+    from scmiac_amd import _hip
+    rng = np.random.default_rng(d)
+    centres = rng.normal(size=(5, d)) * 2
+    r = (centres[rng.integers(0, 5, m)] + rng.normal(size=(m, d))).astype(np.float32)
+    q = (centres[rng.integers(0, 5, n)] + rng.normal(size=(n, d))).astype(np.float32)
+    q[:10] = r[:10]
+    idx_o, d2_o = oracle.knn_dist2(q, r, k)
+    st = _hip.knn_search(torch.from_numpy(q).cuda(), torch.from_numpy(r).cuda(), k)
+    np.testing.assert_array_equal(st.idx.cpu().numpy(), idx_o)
+    np.testing.assert_array_equal(st.dist2.cpu().numpy(), d2_o)
+    y = (q + 2.0 * rng.normal(size=q.shape)).astype(np.float32)
+    np.testing.assert_array_equal(_hip.closer_count(torch.from_numpy(q).cuda(), torch.from_numpy(y).cuda()).cpu().numpy(),
+                                  oracle.closer_count(q, y).astype(np.int64))
+
+
+def test_filter_anchor_with_its_default_neighbour_count():
+    """``filter_anchor`` (anchors.py:584-628) with k_filter=200 on a 230-gene feature set:
+    anchors survive iff the reference cell is among the query cell's 200 nearest cells in
+    the row-normalised feature space."""
+    from sklearn.preprocessing import normalize
+
+    class _Ad:
+        def __init__(self, X):
+            self.X = X
+
+    rng = np.random.default_rng(12)
+    genes, feats = 400, np.sort(rng.choice(400, 230, replace=False))
+    prof = rng.gamma(2.0, 1.0, size=(6, genes))
+    l1, l2 = rng.integers(0, 6, 1500), rng.integers(0, 6, 1300)
+    X1 = np.log1p(rng.poisson(prof[l1])).astype(np.float64)
+    X2 = np.log1p(rng.poisson(prof[l2])).astype(np.float64)
+    anchors = np.stack([rng.integers(0, 1500, 4000), rng.integers(0, 1300, 4000)], axis=1)
+    got = A.filter_anchor(anchors, adata_ref=_Ad(X1), adata_qry=_Ad(X2), high_dim_feature=feats, k_filter=200)
+    ref_data, qry_data = normalize(X1[:, feats], axis=1), normalize(X2[:, feats], axis=1)
+    G = oracle.knn(qry_data, ref_data, 200)[0]
+    want = np.array([xx for xx in anchors if xx[0] in G[xx[1]]])
+    np.testing.assert_array_equal(got, want)
+    assert 0 < len(want) < len(anchors)
