@@ -64,6 +64,9 @@ def partially_matched_foscttm(x, y, x_barcodes, y_barcodes):
 
 def _self_knn(data, k):
     d = _dev(data)
+    if k > _hip.KNN_MAX_K:
+        from ..wide_knn import knn_search_wide
+        return knn_search_wide(d, d, k)[0]
     return _hip.knn_search(d, d, k).idx
 
 

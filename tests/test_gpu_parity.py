@@ -162,7 +162,7 @@ def test_knn_rejects_bad_arguments():
     with pytest.raises(ValueError):
         _hip.knn_search(q, q, 65)
     with pytest.raises(ValueError):
-        _hip.knn_search(torch.zeros((4, 200), device="cuda"), torch.zeros((4, 200), device="cuda"), 3)
+        _hip.knn_search(torch.zeros((4, 257), device="cuda"), torch.zeros((4, 257), device="cuda"), 3)
     with pytest.raises(ValueError):
         _hip.knn_search(q, torch.zeros((4, 9), device="cuda"), 3)
 
