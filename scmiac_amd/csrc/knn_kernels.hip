@@ -654,14 +654,14 @@ __global__ __launch_bounds__(EX_NT) void exact_rows_kernel(
 // --------------------------------------------------------------------------------
 // host-side launchers
 // --------------------------------------------------------------------------------
-static const int kD2Sizes[] = {8, 15, 16, 20, 25, 32, 40, 50, 64, 96, 128};
+static const int kD2Sizes[] = {8, 15, 16, 20, 25, 32, 40, 50, 64, 80, 96, 112, 128};
 // compiled (D2, waves per block, reference rows per LDS stage, pending candidates per query,
 // pending candidates in global memory)
 #define SCMIAC_FUSED_VARIANTS(X) \
     X(8, 12, 320, 32, 1) X(15, 12, 320, 32, 1) X(16, 12, 320, 32, 1) X(20, 12, 320, 32, 1) X(25, 12, 320, 32, 1) \
     X(32, 12, 256, 32, 1) \
     X(40, 12, 128, 32, 1) X(50, 12, 128, 32, 1) X(64, 8, 128, 32, 1) \
-    X(96, 8, 64, 32, 1) X(128, 8, 64, 32, 1) \
+    X(80, 8, 64, 32, 1) X(96, 8, 64, 32, 1) X(112, 8, 64, 32, 1) X(128, 8, 64, 32, 1) \
     X(25, 12, 128, 32, 0) X(25, 12, 128, 32, 1) X(25, 12, 256, 16, 1) X(25, 12, 256, 32, 1)
 
 int knn_pick_d2(int d) {

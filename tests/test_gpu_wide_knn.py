@@ -53,7 +53,8 @@ def test_index_object_serves_wide_queries():
     np.testing.assert_array_equal(graph, oracle.knn_dist2(data, data, 100)[0])
 
 
-@pytest.mark.parametrize("n,m,d,k", [(600, 7000, 129, 30), (500, 6000, 192, 31), (400, 5000, 200, 30), (300, 4000, 256, 64)])
+@pytest.mark.parametrize("n,m,d,k", [(600, 7000, 129, 30), (450, 5000, 160, 30), (500, 6000, 192, 31), (400, 5000, 200, 30),
+                                     (350, 4000, 224, 30), (300, 4000, 256, 64)])
 def test_wide_feature_rows_match_oracle(n, m, d, k):
     """129..256 features per row (8 waves per block, 64-row stages)."""
     from scmiac_amd import _hip
