@@ -658,11 +658,11 @@ static const int kD2Sizes[] = {8, 15, 16, 20, 25, 32, 40, 50, 64, 80, 96, 112, 1
 // compiled (D2, waves per block, reference rows per LDS stage, pending candidates per query,
 // pending candidates in global memory)
 #define SCMIAC_FUSED_VARIANTS(X) \
-    X(8, 12, 320, 32, 1) X(15, 12, 320, 32, 1) X(16, 12, 320, 32, 1) X(20, 12, 320, 32, 1) X(25, 12, 320, 32, 1) \
-    X(32, 12, 256, 32, 1) \
-    X(40, 12, 128, 32, 1) X(50, 12, 128, 32, 1) X(64, 8, 128, 32, 1) \
-    X(80, 8, 64, 32, 1) X(96, 8, 64, 32, 1) X(112, 8, 64, 32, 1) X(128, 8, 64, 32, 1) \
-    X(25, 12, 128, 32, 0) X(25, 12, 128, 32, 1) X(25, 12, 256, 16, 1) X(25, 12, 256, 32, 1)
+    X(8, 12, 320, 64, 1) X(15, 12, 320, 64, 1) X(16, 12, 320, 64, 1) X(20, 12, 320, 64, 1) X(25, 12, 320, 64, 1) \
+    X(32, 12, 256, 64, 1) \
+    X(40, 12, 128, 64, 1) X(50, 12, 128, 64, 1) X(64, 8, 128, 64, 1) \
+    X(80, 8, 64, 64, 1) X(96, 8, 64, 64, 1) X(112, 8, 64, 64, 1) X(128, 8, 64, 64, 1) \
+    X(25, 12, 128, 32, 0) X(25, 12, 128, 32, 1) X(25, 12, 256, 16, 1) X(25, 12, 256, 32, 1) X(25, 12, 320, 32, 1)
 
 int knn_pick_d2(int d) {
     int need = (d + 1) / 2;
@@ -694,7 +694,7 @@ static void fused_variant(int D2, int* nw, int* rt, int* pcap, int* gp) {
     // (fewer barriers, and the waves' uneven candidate work averages out over a longer stage).
     *nw = (D2 <= 50) ? 12 : 8;
     *rt = (D2 <= 25) ? 320 : (D2 <= 32) ? 256 : (D2 <= 64) ? 128 : 64;
-    *pcap = 32;
+    *pcap = 64;  // 64 pending candidates per query: half as many merges as with 32
     *gp = 1;
     if (const char* v = getenv("SCMIAC_FUSED_VARIANT")) {  // tuning aid: "NWxRTxPCAPxGP", e.g. 12x256x32x1
         int a = 0, b = 0, c = 32, e = 0;
