@@ -247,6 +247,13 @@ def main():
     f2["minmax_out"] = ref.min_max([int(v) for v in f2["minmax_in"]])
     with np.errstate(all="ignore"):  # degenerate p90 == p1 -> nan, kept as the reference yields it
         f2["minmax_const_out"] = ref.min_max([7] * 50)
+    # the local-structure branch (k_local): drawn last so the arrays above stay as they were
+    Gp1 = rng.integers(0, 60, size=(n1, 20), dtype=np.int32)
+    Gp2 = rng.integers(0, 70, size=(n2, 20), dtype=np.int32)
+    dfl = ref.score_anchor(pairs, G11, G12, G21, G22, k_score=30, Gp1=Gp1, Gp2=Gp2, k_local=20)
+    f2.update(Gp1=Gp1, Gp2=Gp2, local_score=dfl["score"].values.astype(np.float64),
+              local_1=dfl["score_local1"].values.astype(np.float64),
+              local_2=dfl["score_local2"].values.astype(np.float64))
     np.savez_compressed(out / "f2_score_anchor.npz", **f2)
 
     # ---- F3: find_neighbor on Gaussian mixtures --------------------------------

@@ -135,22 +135,22 @@ def _snn_raw(anchor, G11, G12, G21, G22, k_score):
 def score_anchor(anchor, G11, G12, G21, G22, k_score=30, Gp1=None, Gp2=None, k_local=50):
     """Shared-nearest-neighbour anchor score (anchors.py:631-679):
     ``DataFrame[x1, x2, score]`` (+ the local-structure columns when ``k_local``)."""
-    tmp = _snn_raw(anchor, G11, G12, G21, G22, k_score)
-    anchor_df = pd.DataFrame(anchor, columns=["x1", "x2"])
-    anchor_df["score"] = min_max(tmp)
+    table = pd.DataFrame(anchor, columns=["x1", "x2"])
+    table["score"] = min_max(_snn_raw(anchor, G11, G12, G21, G22, k_score))
+    if not k_local:
+        return table
 
-    if k_local:
-        # intra-dataset agreement; off the product path (find_anchors passes k_local=None)
-        share_nn = np.array([len(set(Gp1[i]).intersection(G11[i, :k_local])) for i in range(len(Gp1))])
-        tmp = [share_nn[xx] for xx in anchor_df["x1"].values]
-        anchor_df["score_local1"] = min_max(tmp)
+    # intra-dataset agreement (off the product path: find_anchors passes k_local=None): how many
+    # of a cell's local neighbours are also among its first k_local neighbours in the joint space
+    def local_agreement(local, joint, cells):
+        shared = np.fromiter((len(set(own) & set(row[:k_local])) for own, row in zip(local, joint)),
+                             dtype=np.int64, count=len(local))
+        return min_max([shared[c] for c in cells])
 
-        share_nn = np.array([len(set(Gp2[i]).intersection(G22[i, :k_local])) for i in range(len(Gp2))])
-        tmp = [share_nn[xx] for xx in anchor_df["x2"].values]
-        anchor_df["score_local2"] = min_max(tmp)
-
-        anchor_df["score"] = anchor_df["score"] * anchor_df["score_local1"] * anchor_df["score_local2"]
-    return anchor_df
+    table["score_local1"] = local_agreement(Gp1, G11, table["x1"].values)
+    table["score_local2"] = local_agreement(Gp2, G22, table["x2"].values)
+    table["score"] = table["score"] * table["score_local1"] * table["score_local2"]
+    return table
 
 
 def filter_anchor(anchor, adata_ref=None, adata_qry=None, scale_ref=False, scale_qry=False,
@@ -170,12 +170,11 @@ def filter_anchor(anchor, adata_ref=None, adata_qry=None, scale_ref=False, scale
 
     ref_data = _prep(adata_ref, scale_ref)
     qry_data = _prep(adata_qry, scale_qry)
-    index = NNDescent(ref_data, metric="euclidean", n_neighbors=k_filter)
-    G = index.query(qry_data, k=k_filter)[0]
-    input_anchors = anchor.shape[0]
-    anchor = np.array([xx for xx in anchor if (xx[0] in G[xx[1]])])
-    print(f"Anchor selected with high CC feature graph: {anchor.shape[0]} / {input_anchors}")
-    return anchor
+    neighbours = NNDescent(ref_data, metric="euclidean", n_neighbors=k_filter).query(qry_data, k=k_filter)[0]
+    n_before = anchor.shape[0]
+    kept = np.array([pair for pair in anchor if pair[0] in neighbours[pair[1]]])
+    print(f"Anchor selected with high CC feature graph: {kept.shape[0]} / {n_before}")
+    return kept
 
 
 # -------------------------------------------------------------- upstream producer
@@ -220,51 +219,50 @@ def cca(data1, data2, scale1=True, scale2=True, n_components=50, max_cc_cell=200
 
 
 def top_features_idx(data, n_features):
-    """Features with the highest absolute loadings over the components (anchors.py:132-168)."""
-    n_cc = data.shape[0]
-    n_features_per_dim = min(n_features * 10 // n_cc, data.shape[1] - 1)
-    sample_range = np.arange(n_cc)[:, None]
-    data = np.abs(data)
-    idx = np.argpartition(-data, n_features_per_dim, axis=1)[:, :n_features_per_dim]
-    idx = idx[sample_range, np.argsort(-data[sample_range, idx], axis=1)]
-    for i in range(n_features // n_cc + 1, n_features_per_dim):
-        features_idx = np.unique(idx[:, :i].flatten())
-        if len(features_idx) > n_features:
-            return features_idx
-    return np.unique(idx[:, :n_features_per_dim].flatten())
+    """Features with the highest absolute loadings over the components (anchors.py:132-168):
+    per component the features ranked by |loading|; the shortest common rank prefix whose
+    union over the components exceeds ``n_features`` features is returned (sorted, unique)."""
+    loadings = np.abs(data)
+    n_comp, n_all = loadings.shape
+    depth = min(n_features * 10 // n_comp, n_all - 1)
+    rows = np.arange(n_comp)[:, None]
+    top = np.argpartition(-loadings, depth, axis=1)[:, :depth]          # the `depth` largest, unordered
+    ranked = top[rows, np.argsort(-loadings[rows, top], axis=1)]        # ... ordered by loading
+    for prefix in range(n_features // n_comp + 1, depth):
+        chosen = np.unique(ranked[:, :prefix].ravel())
+        if chosen.size > n_features:
+            return chosen
+    return np.unique(ranked.ravel())
 
 
 def get_cca_adata_list(adatas, all_nfeatures=3000, single_nfeatures=3000):
-    """Shared highly-variable-gene selection by rank sum (anchors.py:26-90); needs scanpy."""
+    """Genes for the CCA (anchors.py:26-90): among the genes all data sets share, the
+    ``all_nfeatures`` with the smallest sum of per-data-set ranks of normalised dispersion
+    (scanpy's "seurat" flavour).  Returns the raw-count AnnData objects cut to those genes.
+    Needs scanpy."""
     try:
         import scanpy as sc
     except ImportError as exc:  # pragma: no cover - scanpy is an optional dependency
         raise ImportError("get_cca_adata_list needs scanpy (highly_variable_genes)") from exc
 
-    adata_raw_list = []
+    raws = []
     for adata in adatas:
-        adata_raw = adata.raw.to_adata()
-        adata_raw.raw = adata_raw
-        adata_raw_list.append(adata_raw)
+        raw = adata.raw.to_adata()
+        raw.raw = raw
+        raws.append(raw)
+    shared = set(raws[0].var_names).intersection(*(set(r.var_names) for r in raws[1:]))
+    shared = pd.Index(list(shared))
+    print(f"Number of common genes: {len(shared)}")
 
-    common_genes = set(adata_raw_list[0].var_names)
-    for adata_raw in adata_raw_list[1:]:
-        common_genes &= set(adata_raw.var_names)
-    common_genes = pd.Index(list(common_genes))
-    print(f"Number of common genes: {len(common_genes)}")
-
-    gene_rank_df = pd.DataFrame(index=common_genes)
-    for idx, adata_raw in enumerate(adata_raw_list, start=1):
-        sc.pp.highly_variable_genes(adata_raw, flavor="seurat", n_top_genes=single_nfeatures, inplace=True)
-        hvgs_sorted = adata_raw.var.loc[common_genes].sort_values(by="dispersions_norm", ascending=False)
-        hvgs_sorted = hvgs_sorted.reset_index()
-        hvgs_sorted["rank"] = np.arange(1, len(hvgs_sorted) + 1)
-        gene_rank_df[f"adata{idx}_rank"] = hvgs_sorted.set_index("index")["rank"]
-
-    gene_rank_df["rank_sum"] = gene_rank_df.sum(axis=1)
-    gene_rank_df = gene_rank_df.sort_values(by="rank_sum", ascending=True)
-    selected_features = gene_rank_df.nsmallest(all_nfeatures, "rank_sum").index.tolist()
-    return [adata_raw[:, selected_features].copy() for adata_raw in adata_raw_list]
+    ranks = pd.DataFrame(index=shared)
+    for pos, raw in enumerate(raws, start=1):
+        sc.pp.highly_variable_genes(raw, flavor="seurat", n_top_genes=single_nfeatures, inplace=True)
+        order = raw.var.loc[shared].sort_values(by="dispersions_norm", ascending=False).index
+        ranks[f"adata{pos}_rank"] = pd.Series(np.arange(1, len(order) + 1), index=order)
+    ranks["rank_sum"] = ranks.sum(axis=1)
+    ranks = ranks.sort_values(by="rank_sum", ascending=True)
+    genes = ranks.nsmallest(all_nfeatures, "rank_sum").index.tolist()
+    return [raw[:, genes].copy() for raw in raws]
 
 
 # ------------------------------------------------------------------ orchestration
@@ -274,43 +272,33 @@ class SeuratIntegration:
     ``.raw_anchor``, ``.U``, ``.V``."""
 
     def __init__(self, n_jobs=-1, random_state=0):
-        self.n_jobs = n_jobs
-        self.k_local = None
-        self.key_local = None
-        self.local_knn = []
-        self.adata_dict = OrderedDict()
-        self.n_dataset = 0
-        self.n_cells = []
-        self.alignments = None
-        self.all_pairs = np.array([])
-        self.anchor = {}
-        self.mutual_knn = {}
-        self.raw_anchor = {}
+        self.n_jobs, self.random_state = n_jobs, random_state
+        # the data sets and what find_anchor is asked for
+        self.adata_dict, self.n_dataset, self.n_cells = OrderedDict(), 0, []
+        self.k_local, self.key_local, self.local_knn = None, None, []
+        self.alignments, self.all_pairs = None, np.array([])
+        # results, keyed by the pair of data-set numbers
+        self.anchor, self.mutual_knn, self.raw_anchor = {}, {}, {}
         self.label_transfer_results = {}
-        self.random_state = random_state
         # device-resident result of the last pairwise search, for the label filter
         self.device_scores = {}
 
     def _calculate_local_knn(self):
-        if self.k_local is not None:
-            print("Find neighbors within datasets")
-            for adata in self.adata_dict.values():
-                index = NNDescent(adata.obsm[self.key_local], metric="euclidean",
-                                  n_neighbors=self.k_local + 1, random_state=self.random_state)
-                self.local_knn.append(index.neighbor_graph[0][:, 1:])
-        else:
-            self.local_knn = [None for _ in self.adata_dict.values()]
+        if self.k_local is None:
+            self.local_knn = [None] * len(self.adata_dict)
+            return
+        print("Find neighbors within datasets")
+        for adata in self.adata_dict.values():
+            graph = NNDescent(adata.obsm[self.key_local], metric="euclidean", n_neighbors=self.k_local + 1,
+                              random_state=self.random_state).neighbor_graph[0]
+            self.local_knn.append(graph[:, 1:])  # column 0 is the cell itself
 
     def _get_all_pairs(self):
-        if self.alignments is not None:
-            all_pairs = []
-            for pair in self.alignments:
-                for xx in pair[0]:
-                    for yy in pair[1]:
-                        all_pairs.append(f"{min(xx, yy)}-{max(xx, yy)}")
-            self.all_pairs = np.unique(all_pairs)
-        else:
+        if self.alignments is None:
             self.all_pairs = np.array([])
+            return
+        names = [f"{min(a, b)}-{max(a, b)}" for left, right in self.alignments for a in left for b in right]
+        self.all_pairs = np.unique(names)
 
     def _prepare_matrix(self, i, j, key_anchor):
         adata1, adata2 = self.adata_dict[i], self.adata_dict[j]
@@ -410,23 +398,19 @@ class SeuratIntegration:
         cells) and their Gaussian-kernel weights (anchors.py:1189-1241).  Returns
         ``(anchor, G, D, cum_qry)`` like the reference."""
         print("Initialize")
-        cum_ref, cum_qry = [0], [0]
-        for xx in ref:
-            cum_ref.append(cum_ref[-1] + data[xx].shape[0])
-        for xx in qry:
-            cum_qry.append(cum_qry[-1] + data[xx].shape[0])
+        # row offsets of the data sets inside the concatenated reference / query matrices
+        cum_ref = [0] + [int(v) for v in np.cumsum([data[r].shape[0] for r in ref])]
+        cum_qry = [0] + [int(v) for v in np.cumsum([data[q].shape[0] for q in qry])]
 
         frames = []
-        for i, xx in enumerate(ref):
-            for jj, yy in enumerate(qry):
-                if xx < yy:
-                    tmp = self.anchor[(xx, yy)].copy()
-                else:  # stored the other way round: swap the two index columns
-                    tmp = self.anchor[(yy, xx)].copy()
-                    tmp[["x1", "x2"]] = tmp[["x2", "x1"]]
-                tmp["x1"] += cum_ref[i]
-                tmp["x2"] += cum_qry[jj]
-                frames.append(tmp)
+        for ri, r in enumerate(ref):
+            for qi, q in enumerate(qry):
+                stored = self.anchor[(min(r, q), max(r, q))].copy()
+                if r > q:  # stored the other way round: swap the two index columns
+                    stored[["x1", "x2"]] = stored[["x2", "x1"]]
+                stored["x1"] += cum_ref[ri]
+                stored["x2"] += cum_qry[qi]
+                frames.append(stored)
         table = pd.concat(frames)
         score = table["score"].values
         anchor = table[["x1", "x2"]].values
@@ -445,12 +429,13 @@ class SeuratIntegration:
         G, D = index.query(reduce_qry, k=k_weight)
 
         print("Normalize graph")
-        cell_filter = D[:, -1] == 0
-        D = (1 - D / D[:, -1][:, None]) * score[G]
-        D[cell_filter] = score[G[cell_filter]]
-        D = 1 - np.exp(-D * (sd ** 2) / 4)
-        D = D / (np.sum(D, axis=1) + 1e-6)[:, None]
-        return anchor, G, D, cum_qry
+        farthest = D[:, -1]
+        all_on_cell = farthest == 0                     # every listed anchor sits on the cell itself
+        W = (1 - D / farthest[:, None]) * score[G]      # closeness relative to the farthest, times anchor score
+        W[all_on_cell] = score[G[all_on_cell]]
+        W = 1 - np.exp(-W * (sd ** 2) / 4)
+        W = W / (np.sum(W, axis=1) + 1e-6)[:, None]
+        return anchor, G, W, cum_qry
 
     def find_anchor(self, adata_list, adata_names=None, k_local=None, key_local="X_pca", key_anchor="X",
                     dim_red="pca", svd_algorithm="randomized", scale1=True, scale2=True, scale_list=None,

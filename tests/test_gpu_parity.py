@@ -238,6 +238,18 @@ def test_find_anchor_precomputed_golden(golden, capsys):
     assert "Find Anchors using k=30" in capsys.readouterr().out
 
 
+def test_score_anchor_local_branch_golden(golden):
+    """``score_anchor`` with ``k_local`` (anchors.py:670-678): the three score columns of the
+    reference, bit for bit."""
+    f = golden["f2_score_anchor"]
+    df = A.score_anchor(f["pairs"], f["G11"], f["G12"], f["G21"], f["G22"], k_score=30,
+                        Gp1=f["Gp1"], Gp2=f["Gp2"], k_local=20)
+    assert list(df.columns) == ["x1", "x2", "score", "score_local1", "score_local2"]
+    np.testing.assert_array_equal(df["score_local1"].values, f["local_1"])
+    np.testing.assert_array_equal(df["score_local2"].values, f["local_2"])
+    np.testing.assert_array_equal(df["score"].values, f["local_score"])
+
+
 def test_find_nearest_anchor_golden(golden):
     """100 nearest anchors per query cell and their weights (anchors.py:1189-1241) against
     the reference's own method run on the exact stand-in index."""

@@ -33,6 +33,15 @@ def test_score_anchor_matches_reference(golden):
         np.testing.assert_array_equal(df["score"].values, f[f"score_ks{ks}"])  # bit-exact
 
 
+def test_score_anchor_local_branch_matches_reference(golden):
+    f = golden["f2_score_anchor"]
+    df = oracle.score_anchor(f["pairs"], f["G11"], f["G12"], f["G21"], f["G22"], k_score=30,
+                             Gp1=f["Gp1"], Gp2=f["Gp2"], k_local=20)
+    np.testing.assert_array_equal(df["score_local1"].values, f["local_1"])
+    np.testing.assert_array_equal(df["score_local2"].values, f["local_2"])
+    np.testing.assert_array_equal(df["score"].values, f["local_score"])
+
+
 def test_min_max_matches_reference(golden):
     f = golden["f2_score_anchor"]
     out = oracle.min_max([int(v) for v in f["minmax_in"]])
