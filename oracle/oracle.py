@@ -217,18 +217,16 @@ def snn_counts_loops(anchor, G11, G12, G21, G22, k_score=30):
 
 def score_anchor(anchor, G11, G12, G21, G22, k_score=30, Gp1=None, Gp2=None, k_local=50):
     """anchors.py:631-679 (``k_local`` branch included for completeness)."""
-    tmp = [int(v) for v in snn_counts(anchor, G11, G12, G21, G22, k_score)]
-    anchor_df = pd.DataFrame(anchor, columns=["x1", "x2"])
-    anchor_df["score"] = min_max(tmp)
+    table = pd.DataFrame(anchor, columns=["x1", "x2"])
+    table["score"] = min_max([int(v) for v in snn_counts(anchor, G11, G12, G21, G22, k_score)])
     if k_local:
-        share_nn = np.array([len(set(Gp1[i]).intersection(G11[i, :k_local])) for i in range(len(Gp1))])
-        tmp = [share_nn[xx] for xx in anchor_df["x1"].values]
-        anchor_df["score_local1"] = min_max(tmp)
-        share_nn = np.array([len(set(Gp2[i]).intersection(G22[i, :k_local])) for i in range(len(Gp2))])
-        tmp = [share_nn[xx] for xx in anchor_df["x2"].values]
-        anchor_df["score_local2"] = min_max(tmp)
-        anchor_df["score"] = anchor_df["score"] * anchor_df["score_local1"] * anchor_df["score_local2"]
-    return anchor_df
+        for col, local, joint, cells in (("score_local1", Gp1, G11, table["x1"].values),
+                                         ("score_local2", Gp2, G22, table["x2"].values)):
+            # per cell: how many local neighbours are among its first k_local joint-space ones
+            shared = np.array([len(set(own) & set(row[:k_local])) for own, row in zip(local, joint)])
+            table[col] = min_max([shared[c] for c in cells])
+        table["score"] = table["score"] * table["score_local1"] * table["score_local2"]
+    return table
 
 
 # ---------------------------------------------------------------- upstream producer
