@@ -1,0 +1,64 @@
+"""Randomised parity sweep: k-NN tables and closer-than-match counts on the GPU against
+the CPU oracle over random shapes (every feature-dimension bucket of the kernels, ragged
+row counts, duplicates, unit rows).  Exits non-zero on the first difference.
+
+    python tools/stress_parity.py [--cases 60] [--seed 0]
+"""
+import argparse
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+from oracle import oracle  # noqa: E402  (checker)
+from scmiac_amd import _hip  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=60)
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    rng = np.random.default_rng(a.seed)
+    oracle.build()
+    t0 = time.time()
+    for case in range(a.cases):
+        d = int(rng.choice([1, 2, 3, 7, 16, 17, 30, 31, 33, 40, 41, 50, 51, 64, 65, 80, 81, 100, 101, 128, 129, 160,
+                            161, 192, 200, 224, 225, 256]))
+        n = int(rng.integers(1, 3000))
+        m = int(rng.integers(1, 40000))
+        k = int(min(m, rng.integers(1, 65)))
+        nc = int(rng.integers(1, 12))
+        centres = rng.normal(size=(nc, d)) * rng.uniform(0.1, 4)
+        r = (centres[rng.integers(0, nc, m)] + rng.normal(size=(m, d)) * rng.uniform(0.01, 2)).astype(np.float32)
+        q = (centres[rng.integers(0, nc, n)] + rng.normal(size=(n, d)) * rng.uniform(0.01, 2)).astype(np.float32)
+        if rng.random() < 0.3:
+            r /= np.maximum(np.linalg.norm(r, axis=1, keepdims=True), 1e-6)
+            q /= np.maximum(np.linalg.norm(q, axis=1, keepdims=True), 1e-6)
+        if rng.random() < 0.4 and m > 20:
+            r[rng.integers(0, m, 10)] = r[rng.integers(0, m)]      # duplicated references
+            q[: min(n, 5)] = r[: min(n, 5)]                        # queries sitting on references
+        if rng.random() < 0.2:
+            r *= 1e3
+            q *= 1e3
+        qd, rd = torch.from_numpy(q).cuda(), torch.from_numpy(r).cuda()
+        idx_o, d2_o = oracle.knn_dist2(q, r, k)
+        st = _hip.knn_search(qd, rd, k)
+        ok = np.array_equal(st.idx.cpu().numpy(), idx_o) and np.array_equal(st.dist2.cpu().numpy(), d2_o)
+        match = rng.integers(0, m, n).astype(np.int32)
+        cnt_o = oracle.closer_count(q, r, match)
+        cnt = _hip.closer_count(qd, rd, match=torch.from_numpy(match).cuda()).cpu().numpy()
+        ok2 = np.array_equal(cnt, cnt_o.astype(np.int64))
+        print(f"case {case:3d} n={n:5d} m={m:6d} d={d:3d} k={k:2d}  knn {'ok' if ok else 'DIFFERS'}  "
+              f"count {'ok' if ok2 else 'DIFFERS'}  uncertified={int(st.n_uncertified.item())}", flush=True)
+        if not (ok and ok2):
+            sys.exit(1)
+    print(f"{a.cases} cases identical in {time.time() - t0:.0f} s")
+
+
+if __name__ == "__main__":
+    main()
