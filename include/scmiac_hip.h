@@ -209,19 +209,23 @@ SCMIAC_API int scmiac_closer_count(const float *q, int64_t n, const float *r, in
  * backward, one launch each.  zi, zj: float32 [batch, d] row-major on the device,
  * 1 <= d <= 64, batch >= 1.  Rows are L2-normalised inside (x / max(|x|, 1e-12)).
  *
- * forward: loss_parts[scmiac_ntxent2_parts(batch)] receives per-block partial sums
- * whose total is the loss; lse_row / lse_col (float32 [batch]) receive the row and
- * column log-sum-exp of the similarity matrix, which backward reads.
+ * forward: loss_parts[scmiac_ntxent2_parts(batch)] receives partial sums whose total
+ * is the loss; lse_row / lse_col (float32 [batch]) receive the row and column
+ * log-sum-exp of the similarity matrix, which backward reads.
  * backward: grad_out points at one float32 on the device (d loss); dzi, dzj receive
  * d loss / d zi, d loss / d zj.  The batch x batch similarity matrix is recomputed, not
- * stored.
+ * stored.  Both take scmiac_ntxent2_workspace_size(batch, d) bytes of device scratch
+ * (partial results of the up to 16 slices the other side's rows are cut into).
  */
 SCMIAC_API int scmiac_ntxent2_parts(int64_t batch);
+SCMIAC_API int scmiac_ntxent2_workspace_size(int64_t batch, int d, size_t *bytes);
 SCMIAC_API int scmiac_ntxent2_forward(const float *zi, const float *zj, int64_t batch, int d, float temperature,
-                                      float *lse_row, float *lse_col, float *loss_parts, void *stream);
+                                      float *lse_row, float *lse_col, float *loss_parts, void *workspace,
+                                      size_t workspace_bytes, void *stream);
 SCMIAC_API int scmiac_ntxent2_backward(const float *zi, const float *zj, int64_t batch, int d, float temperature,
                                        const float *lse_row, const float *lse_col, const float *grad_out,
-                                       float *dzi, float *dzj, void *stream);
+                                       float *dzi, float *dzj, void *workspace, size_t workspace_bytes,
+                                       void *stream);
 
 #ifdef __cplusplus
 }

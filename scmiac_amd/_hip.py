@@ -45,8 +45,10 @@ _SIGNATURES = {
     "scmiac_closer_count_workspace_size": ([_i64, _i64, _i32, _c.POINTER(_sz)], _c.c_int),
     "scmiac_closer_count": ([_vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _sz, _vp], _c.c_int),
     "scmiac_ntxent2_parts": ([_i64], _c.c_int),
-    "scmiac_ntxent2_forward": ([_vp, _vp, _i64, _i32, _c.c_float, _vp, _vp, _vp, _vp], _c.c_int),
-    "scmiac_ntxent2_backward": ([_vp, _vp, _i64, _i32, _c.c_float, _vp, _vp, _vp, _vp, _vp, _vp], _c.c_int),
+    "scmiac_ntxent2_workspace_size": ([_i64, _i32, _c.POINTER(_sz)], _c.c_int),
+    "scmiac_ntxent2_forward": ([_vp, _vp, _i64, _i32, _c.c_float, _vp, _vp, _vp, _vp, _sz, _vp], _c.c_int),
+    "scmiac_ntxent2_backward": ([_vp, _vp, _i64, _i32, _c.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
+                                _c.c_int),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -282,6 +284,33 @@ def fused_ms():
     return float(ms.value), int(cnt.value)
 
 
+_ntxent_bytes = {}
+
+
+def _ntxent_workspace(lib, batch, d, device):
+    need = _ntxent_bytes.get((batch, d))
+    if need is None:  # the loss runs every training step: ask once per shape
+        nbytes = ctypes.c_size_t(0)
+        _check(lib.scmiac_ntxent2_workspace_size(batch, d, ctypes.byref(nbytes)))
+        need = _ntxent_bytes[(batch, d)] = max(nbytes.value, 256)
+    return _workspace(need, device)
+
+
+class _on_device:
+    """``torch.cuda.device(device)`` without the switch when ``device`` is already current."""
+
+    def __init__(self, device):
+        self._ctx = None if device.index in (None, torch.cuda.current_device()) else torch.cuda.device(device)
+
+    def __enter__(self):
+        if self._ctx is not None:
+            self._ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self._ctx is not None:
+            self._ctx.__exit__(*exc)
+
+
 def ntxent2_forward(zi, zj, temperature):
     """Symmetric NT-Xent loss of two float32 ``[batch, d]`` device tensors.
 
@@ -296,9 +325,10 @@ def ntxent2_forward(zi, zj, temperature):
     parts = torch.empty((max(lib.scmiac_ntxent2_parts(batch), 1),), dtype=torch.float32, device=device)
     lse_row = torch.empty((batch,), dtype=torch.float32, device=device)
     lse_col = torch.empty((batch,), dtype=torch.float32, device=device)
-    with torch.cuda.device(device):
+    ws = _ntxent_workspace(lib, batch, d, device)
+    with _on_device(device):
         _check(lib.scmiac_ntxent2_forward(_ptr(zi), _ptr(zj), batch, d, float(temperature), _ptr(lse_row),
-                                          _ptr(lse_col), _ptr(parts), _stream()))
+                                          _ptr(lse_col), _ptr(parts), _ptr(ws), ws.numel(), _stream()))
     return parts, lse_row, lse_col
 
 
@@ -310,9 +340,11 @@ def ntxent2_backward(zi, zj, temperature, lse_row, lse_col, grad_out):
     grad_out = _dev_f32(grad_out, device).reshape(1)
     batch, d = zi.shape
     dzi, dzj = torch.empty_like(zi), torch.empty_like(zj)
-    with torch.cuda.device(device):
+    ws = _ntxent_workspace(lib, batch, d, device)
+    with _on_device(device):
         _check(lib.scmiac_ntxent2_backward(_ptr(zi), _ptr(zj), batch, d, float(temperature), _ptr(lse_row),
-                                           _ptr(lse_col), _ptr(grad_out), _ptr(dzi), _ptr(dzj), _stream()))
+                                           _ptr(lse_col), _ptr(grad_out), _ptr(dzi), _ptr(dzj), _ptr(ws),
+                                           ws.numel(), _stream()))
     return dzi, dzj
 
 

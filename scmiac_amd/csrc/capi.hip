@@ -333,24 +333,39 @@ static int check_ntxent_args(int64_t batch, int d, float temperature) {
     return SCMIAC_OK;
 }
 
+int scmiac_ntxent2_workspace_size(int64_t batch, int d, size_t* bytes) {
+    if (!bytes) return fail(SCMIAC_ERR_ARG, "bytes is NULL");
+    if (int rc = check_ntxent_args(batch, d, 1.0f)) return rc;
+    *bytes = ntxent2_workspace_bytes((int)batch, d);
+    return SCMIAC_OK;
+}
+
 int scmiac_ntxent2_forward(const float* zi, const float* zj, int64_t batch, int d, float temperature, float* lse_row,
-                           float* lse_col, float* loss_parts, void* stream_) {
+                           float* lse_col, float* loss_parts, void* workspace, size_t workspace_bytes,
+                           void* stream_) {
     if (int rc = check_ntxent_args(batch, d, temperature)) return rc;
-    if (!zi || !zj || !lse_row || !lse_col || !loss_parts) return fail(SCMIAC_ERR_ARG, "NULL device pointer");
+    if (!zi || !zj || !lse_row || !lse_col || !loss_parts || !workspace)
+        return fail(SCMIAC_ERR_ARG, "NULL device pointer");
+    size_t need = ntxent2_workspace_bytes((int)batch, d);
+    if (need > workspace_bytes)
+        return fail(SCMIAC_ERR_WORKSPACE, "workspace holds %zu bytes, %zu needed", workspace_bytes, need);
     HIP_TRY(launch_ntxent2_forward(zi, zj, (int)batch, d, temperature, lse_row, lse_col, loss_parts,
-                                   static_cast<hipStream_t>(stream_)),
+                                   static_cast<float*>(workspace), static_cast<hipStream_t>(stream_)),
             "ntxent2_forward");
     return SCMIAC_OK;
 }
 
 int scmiac_ntxent2_backward(const float* zi, const float* zj, int64_t batch, int d, float temperature,
                             const float* lse_row, const float* lse_col, const float* grad_out, float* dzi,
-                            float* dzj, void* stream_) {
+                            float* dzj, void* workspace, size_t workspace_bytes, void* stream_) {
     if (int rc = check_ntxent_args(batch, d, temperature)) return rc;
-    if (!zi || !zj || !lse_row || !lse_col || !grad_out || !dzi || !dzj)
+    if (!zi || !zj || !lse_row || !lse_col || !grad_out || !dzi || !dzj || !workspace)
         return fail(SCMIAC_ERR_ARG, "NULL device pointer");
+    size_t need = ntxent2_workspace_bytes((int)batch, d);
+    if (need > workspace_bytes)
+        return fail(SCMIAC_ERR_WORKSPACE, "workspace holds %zu bytes, %zu needed", workspace_bytes, need);
     HIP_TRY(launch_ntxent2_backward(zi, zj, (int)batch, d, temperature, lse_row, lse_col, grad_out, dzi, dzj,
-                                    static_cast<hipStream_t>(stream_)),
+                                    static_cast<float*>(workspace), static_cast<hipStream_t>(stream_)),
             "ntxent2_backward");
     return SCMIAC_OK;
 }

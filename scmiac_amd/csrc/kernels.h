@@ -89,10 +89,11 @@ hipError_t launch_closer_count(const KnnGeometry& g, const float* Q, const float
 
 // contrastive_kernels.hip
 int ntxent2_blocks(int B);
+size_t ntxent2_workspace_bytes(int B, int d);
 hipError_t launch_ntxent2_forward(const float* zi, const float* zj, int B, int d, float temperature, float* lse_row,
-                                  float* lse_col, float* loss_parts, hipStream_t stream);
+                                  float* lse_col, float* loss_parts, float* ws, hipStream_t stream);
 hipError_t launch_ntxent2_backward(const float* zi, const float* zj, int B, int d, float temperature,
                                    const float* lse_row, const float* lse_col, const float* grad_out, float* dzi,
-                                   float* dzj, hipStream_t stream);
+                                   float* dzj, float* ws, hipStream_t stream);
 
 }  // namespace scmiac

@@ -45,10 +45,11 @@ def test_size_queries_and_argument_checks_without_gpu():
     assert lib.scmiac_closer_count_workspace_size(5000, 7000, 30, ctypes.byref(n)) == 0 and n.value > 7000 * 30 * 4
     assert lib.scmiac_closer_count(None, 10, None, 11, 30, None, None, None, None, 0, None) == 1
     assert b"equal row counts" in lib.scmiac_last_error()
-    assert lib.scmiac_ntxent2_parts(256) == 4 and lib.scmiac_ntxent2_parts(257) == 5
-    assert lib.scmiac_ntxent2_forward(None, None, 8, 65, 0.5, None, None, None, None) == 1
+    assert lib.scmiac_ntxent2_parts(256) == 1 and lib.scmiac_ntxent2_parts(257) == 2
+    assert lib.scmiac_ntxent2_workspace_size(256, 30, ctypes.byref(n)) == 0 and n.value == 16 * 2 * 256 * 32 * 4
+    assert lib.scmiac_ntxent2_forward(None, None, 8, 65, 0.5, None, None, None, None, 0, None) == 1
     assert b"d=65" in lib.scmiac_last_error()
-    assert lib.scmiac_ntxent2_backward(None, None, 8, 30, 0.0, None, None, None, None, None, None) == 1
+    assert lib.scmiac_ntxent2_backward(None, None, 8, 30, 0.0, None, None, None, None, None, None, 0, None) == 1
     assert b"temperature" in lib.scmiac_last_error()
 
 
