@@ -2,7 +2,7 @@
 the CPU oracle over random shapes (every feature-dimension bucket of the kernels, ragged
 row counts, duplicates, unit rows).  Exits non-zero on the first difference.
 
-    python tools/stress_parity.py [--cases 60] [--seed 0]
+    python tools/stress_parity.py [--cases 60] [--seed 0] [--max-n 3000] [--max-m 40000]
 """
 import argparse
 import sys
@@ -22,6 +22,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=60)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--max-n", type=int, default=3000)
+    ap.add_argument("--max-m", type=int, default=40000)
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     oracle.build()
@@ -29,8 +31,8 @@ def main():
     for case in range(a.cases):
         d = int(rng.choice([1, 2, 3, 7, 16, 17, 30, 31, 33, 40, 41, 50, 51, 64, 65, 80, 81, 100, 101, 128, 129, 160,
                             161, 192, 200, 224, 225, 256]))
-        n = int(rng.integers(1, 3000))
-        m = int(rng.integers(1, 40000))
+        n = int(rng.integers(1, a.max_n))
+        m = int(rng.integers(1, a.max_m))
         k = int(min(m, rng.integers(1, 65)))
         nc = int(rng.integers(1, 12))
         centres = rng.normal(size=(nc, d)) * rng.uniform(0.1, 4)
