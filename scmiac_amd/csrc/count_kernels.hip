@@ -59,16 +59,23 @@ __global__ __launch_bounds__(256) void closer_thresholds_kernel(
 }
 
 // what the stage loop does with a finished subtile: nothing, unless some score lies below
-// `hi` (smallest of the lane's 16 scores as a depth-3 tree, as in the k-NN search)
+// `hi` (smallest of the lane's 16 scores as a depth-3 tree, as in the k-NN search).  Where
+// nearly every subtile has such scores the question is not worth its 9 instructions:
+// `dense` (set per stage from the stage before) skips it.
 #define SCMIAC_TEST_PREV(PRV_)                                                                      \
     do {                                                                                            \
-        const float m0_ = min3_after_mfma(accs[PRV_][0], accs[PRV_][1], accs[PRV_][2]);             \
-        const float m1_ = min3_raw_after(accs[PRV_][3], accs[PRV_][4], accs[PRV_][5], m0_);         \
-        const float m2_ = min3_raw_after(accs[PRV_][6], accs[PRV_][7], accs[PRV_][8], m0_);         \
-        const float m3_ = min3_raw_after(accs[PRV_][9], accs[PRV_][10], accs[PRV_][11], m0_);       \
-        const float m4_ = min3_raw_after(accs[PRV_][12], accs[PRV_][13], accs[PRV_][14], m0_);      \
-        const float mn_ = min2_raw(min3_raw(m0_, m1_, m2_), min3_raw(m3_, m4_, accs[PRV_][15]));    \
-        if (__any(mn_ < hi)) count_slow(accs[PRV_], ref0s[PRV_]);                                   \
+        bool go_ = dense;                                                                           \
+        if (!go_) {                                                                                 \
+            const float m0_ = min3_after_mfma(accs[PRV_][0], accs[PRV_][1], accs[PRV_][2]);         \
+            const float m1_ = min3_raw_after(accs[PRV_][3], accs[PRV_][4], accs[PRV_][5], m0_);     \
+            const float m2_ = min3_raw_after(accs[PRV_][6], accs[PRV_][7], accs[PRV_][8], m0_);     \
+            const float m3_ = min3_raw_after(accs[PRV_][9], accs[PRV_][10], accs[PRV_][11], m0_);   \
+            const float m4_ = min3_raw_after(accs[PRV_][12], accs[PRV_][13], accs[PRV_][14], m0_);  \
+            const float mn_ = min2_raw(min3_raw(m0_, m1_, m2_), min3_raw(m3_, m4_, accs[PRV_][15])); \
+            go_ = __any(mn_ < hi);                                                                  \
+            hits += go_ ? 1 : 0;                                                                    \
+        }                                                                                           \
+        if (go_) count_slow(accs[PRV_], ref0s[PRV_]);                                               \
     } while (0)
 
 template <int D2, int NW_, int RT_>
@@ -193,8 +200,13 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
     if (T > 0) SCMIAC_STAGE(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    bool dense = false;  // wave-uniform: skip the per-subtile question in this stage
+    int hits = 0;        // subtiles of the current stage that had scores below `hi`
     for (int t = 0; t < T; ++t) {
         if (t + 1 < T) SCMIAC_STAGE(t + 1, (t + 1) & 1);
+        // asked again every eighth stage, so a stream that turns sparse is noticed
+        dense = (t & 7) != 0 && (dense || hits >= NSUB - 1);
+        hits = 0;
         const float* tb = tile + (t & 1) * RT * LS;
         const float* nb = tnorm + (t & 1) * RT;
         SCMIAC_LOAD_NORMS(0, 0);
