@@ -2,6 +2,6 @@
 device-side consumer of the anchor table (loaders, contrastive loss)."""
 from .scmiac import find_anchors
 from .loss import NTXentLoss2
-from .dataset import DeviceAnchorLoader, DeviceMultiOmicLoader, make_loaders
+from .dataset import DeviceAnchorLoader, DeviceMultiOmicLoader, anchor_frame, make_loaders
 
-__all__ = ["find_anchors", "NTXentLoss2", "DeviceAnchorLoader", "DeviceMultiOmicLoader", "make_loaders"]
+__all__ = ["find_anchors", "NTXentLoss2", "DeviceAnchorLoader", "DeviceMultiOmicLoader", "anchor_frame", "make_loaders"]

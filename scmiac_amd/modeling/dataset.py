@@ -141,6 +141,22 @@ class DeviceAnchorLoader:
             yield batch
 
 
+def anchor_frame(x1, x2, labels=None):
+    """Minimal anchor table for :class:`DeviceAnchorLoader` from index arrays (numpy or
+    device tensors, e.g. the kept pairs of ``anchor_search.filter_anchors``) and, for balanced
+    sampling, the RNA-side labels of all cells: no CSV or score columns needed."""
+    import pandas as pd
+
+    def host(v):
+        return v.cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+
+    x1, x2 = host(x1).astype(np.int64), host(x2).astype(np.int64)
+    frame = pd.DataFrame({"x1": x1, "x2": x2})
+    if labels is not None:
+        frame["x1_ct"] = np.asarray(labels)[x1]
+    return frame
+
+
 def make_loaders(adata_rna, adata_atac, anchor_df, rna_latent_key="X_pca", atac_latent_key="lsi49",
                  batch_size=256, balanced_sampler=True, device=None, seed=None):
     """The two loaders ``preprocess`` builds (``scmiac.py:140-161``), resident on the device."""

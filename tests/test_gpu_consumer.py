@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from oracle import oracle
-from scmiac_amd.modeling.dataset import DeviceAnchorLoader, DeviceMultiOmicLoader, make_loaders
+from scmiac_amd.modeling.dataset import DeviceAnchorLoader, DeviceMultiOmicLoader, anchor_frame, make_loaders
 from scmiac_amd.modeling.loss import NTXentLoss2, ntxent2
 
 pytestmark = pytest.mark.gpu
@@ -158,3 +158,26 @@ def test_balanced_anchor_sampling_and_make_loaders():
     again = make_loaders(_Ad("X_pca", rna), _Ad("lsi49", atac), df, batch_size=256, seed=11)[1]
     anchors.generator.manual_seed(12)
     np.testing.assert_array_equal(anchors.draw().cpu().numpy(), again.draw().cpu().numpy())
+
+
+def test_anchor_loader_from_the_device_side_filter_result():
+    """Anchors straight from the search (index arrays + labels), without a CSV in between."""
+    from scmiac_amd import anchor_search
+
+    rng = np.random.default_rng(2)
+    centres = rng.normal(scale=3.0, size=(5, 20))
+    l1, l2 = rng.integers(0, 5, 600), rng.integers(0, 5, 500)
+    U = (centres[l1] + rng.normal(size=(600, 20))).astype(np.float32)
+    V = (centres[l2] + rng.normal(size=(500, 20))).astype(np.float32)
+    tables = anchor_search.find_neighbor_device(torch.from_numpy(U).cuda(), torch.from_numpy(V).cuda(), 30)
+    scores, n_pairs = anchor_search.mnn_and_score(tables, k_anchor=5, k_score=30)
+    c1, c2 = anchor_search.label_codes(l1, l2)
+    kept = anchor_search.filter_anchors(scores, n_pairs, c1, c2)
+    frame = anchor_frame(kept.x1, kept.x2, labels=l1)
+    loader = DeviceAnchorLoader(U, V, frame, batch_size=64, seed=0)
+    batch = next(iter(loader))
+    assert batch["rna_anchor"].shape == (64, 20) and batch["atac_anchor"].shape == (64, 20)
+    # anchors passed the label filter: both cells of a drawn pair carry the same label
+    codes = batch["ct"].cpu().numpy()
+    assert set(loader.ct_categories[codes]) <= {str(v) for v in range(5)}
+    assert len(loader) == len(kept.x1) // 64
