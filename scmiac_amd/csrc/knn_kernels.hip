@@ -316,14 +316,10 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
             // (key register r holds subtile row (r & 3) + 8 (r >> 2) = r + (r & 12))
             const unsigned kb = __float_as_uint(kmin);
             const uint2 entry = make_uint2(kb, ref0 + (kb & 15u) + (kb & 12u));
+            // there is room: a buffer is merged as soon as it fills up (end of this path)
             const bool p = kmin < tau;
-            if (__builtin_expect(__any(p && pcnt >= (unsigned)HCAP), 0)) {  // rare: make room first, then test again
-                flush_full(true, false);
-                if (p && kmin < tau) { pend_l[pcnt] = entry; ++pcnt; }
-            } else if (p) {
-                pend_l[pcnt] = entry;
-                ++pcnt;
-            }
+            if (p) pend_l[pcnt] = entry;
+            pcnt += p ? 1u : 0u;
             if (diag) { ++dg_iters; dg_npush += __popcll(__ballot(p)); dg_seg2 += (u64)clock64() - ts1; }
         } else {
             if (diag) ++dg_ngen;
@@ -360,6 +356,7 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
                 skipped = still;
             }
         }
+        if (__builtin_expect(__any(pcnt >= (unsigned)HCAP), 0)) flush_full(true, false);  // keep room for next time
         if (diag) dg_slow += (u64)clock64() - ts0;
     };
 
