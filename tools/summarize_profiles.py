@@ -9,6 +9,7 @@ import collections
 import csv
 import glob
 import json
+import os
 import shutil
 from pathlib import Path
 
@@ -25,10 +26,13 @@ def main():
     ap.add_argument("--n-local", type=int, default=1_000_000)
     a = ap.parse_args()
     out_dir = ROOT / "profiles"
-    shutil.copy(glob.glob(f"{a.stats}/*/*_kernel_stats.csv")[0], out_dir / f"{a.tag}_kernel_stats.csv")
+    def newest(pattern):  # a directory may hold the outputs of earlier runs as well
+        return max(glob.glob(pattern), key=os.path.getmtime)
+
+    shutil.copy(newest(f"{a.stats}/*/*_kernel_stats.csv"), out_dir / f"{a.tag}_kernel_stats.csv")
     out = {}
     for d in a.pmc:
-        for r in csv.DictReader(open(glob.glob(f"{d}/*/*_counter_collection.csv")[0])):
+        for r in csv.DictReader(open(newest(f"{d}/*/*_counter_collection.csv"))):
             kn = r["Kernel_Name"].split("(")[0].replace("void ", "")
             if "scmiac" in kn:
                 out.setdefault(kn, collections.defaultdict(float))[r["Counter_Name"]] += float(r["Counter_Value"])
