@@ -154,8 +154,29 @@ SCMIAC_API int scmiac_anchor_filter(const int64_t *pairs, const int64_t *n_pairs
                          void *stream);
 
 /*
- * Diagnostic aid (no counterpart in the reference).  When the environment variable
- * SCMIAC_FUSED_DIAG=1 is set, the fused kernel of scmiac_knn_search writes twelve
+ * Diagnostic and tuning knobs of the fused kernel (no counterpart in the reference; the
+ * library reads no environment variables).  All zero -- the state at load time -- is the
+ * product behaviour; tests and tuning tools set, and reset, them explicitly:
+ *   slots          > 0: plan the grid as if the GPU ran this many blocks at once
+ *   tail_min_rows  > 0: shortest reference chunk the planner may choose (default 8192)
+ *   no_tail        1: do not split the last round's query blocks further
+ *   ablate         ablation bits honoured by the diagnostic kernel instantiation only
+ *                  (1 no selection, 2 no staging, 4 no barrier, 8 empty candidate path,
+ *                  16 candidate arithmetic only): results are then NOT a k-NN table
+ *   diag           1: per-wave counters, see scmiac_knn_diag_region
+ *   nw, rt, pcap, gp  kernel variant (waves per block, rows per LDS stage, pending
+ *                  candidates per query, 1 = pending buffers in global memory); all zero
+ *                  = the library's choice.  A combination that is not compiled for any
+ *                  feature size is rejected with SCMIAC_ERR_ARG; one that is compiled for
+ *                  other feature sizes only is ignored for the rest.
+ * Thread-safe; affects searches planned after the call.
+ */
+SCMIAC_API int scmiac_knn_set_tuning(int slots, int tail_min_rows, int no_tail, int ablate, int diag, int nw,
+                                     int rt, int pcap, int gp);
+
+/*
+ * Diagnostic aid (no counterpart in the reference).  When the `diag` knob of
+ * scmiac_knn_set_tuning is set, the fused kernel of scmiac_knn_search writes twelve
  * uint64 counters per wave into the workspace at `offset`:
  *   {wave cycles, cycles in the candidate path, cycles merging shortlists,
  *    candidate-path entries, shortlist merges, candidates taken, register steps,

@@ -41,6 +41,7 @@ _SIGNATURES = {
                                 _c.POINTER(_c.c_int)], _c.c_int),
     "scmiac_knn_grid_plan": ([_i64, _i64, _i32, _i32, _i32, _c.POINTER(_i64)], _c.c_int),
     "scmiac_knn_set_timing": ([_i32], _c.c_int),
+    "scmiac_knn_set_tuning": ([_i32] * 9, _c.c_int),
     "scmiac_knn_fused_ms": ([_c.POINTER(_c.c_float), _c.POINTER(_c.c_int)], _c.c_int),
     "scmiac_closer_count_workspace_size": ([_i64, _i64, _i32, _c.POINTER(_sz)], _c.c_int),
     "scmiac_closer_count": ([_vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _sz, _vp], _c.c_int),
@@ -84,6 +85,15 @@ def require_gpu():
     if not torch.cuda.is_available():
         raise ScmiacHipError("no HIP device visible: the anchor search runs only on the GPU (no CPU fallback)")
     return load_library()
+
+
+def _cuda_device(t, what):
+    """Device of ``t``, which must be a tensor in GPU memory: the kernels take device
+    pointers, and a host pointer handed to them is a GPU memory fault, not an exception."""
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        where = t.device if isinstance(t, torch.Tensor) else type(t).__name__
+        raise ValueError(f"{what} must be a tensor on a GPU device (got {where}); there is no CPU path")
+    return t.device
 
 
 def _ptr(t):
@@ -169,7 +179,7 @@ def knn_exact_rows(q, r, k, rows, n_rows, state, *, col_offset=0, scratch_rows=6
     """Direct-evaluation merge of reference block ``r`` into ``state`` for the listed rows.
     ``scratch_rows`` listed rows get 128 KiB of scratch each and are scanned GPU-wide."""
     lib = require_gpu()
-    device = state.idx.device
+    device = _cuda_device(state.idx, "state")
     q = _dev_f32(q, device)
     r = _dev_f32(r, device)
     nbytes = int(scratch_rows) * 128 * 1024
@@ -185,7 +195,7 @@ def knn_exact_rows(q, r, k, rows, n_rows, state, *, col_offset=0, scratch_rows=6
 def find_mnn(g12, g21, ka):
     """Device MNN search; returns ``(pairs int64 [n1*ka, 2], n_pairs int64 [1], status int32 [1])``."""
     lib = require_gpu()
-    device = g12.device
+    device = _cuda_device(g12, "g12")
     g12 = _dev_i32(g12, device)
     g21 = _dev_i32(g21, device)
     n1, ld12 = g12.shape
@@ -205,7 +215,8 @@ def find_mnn(g12, g21, ka):
 def snn_score(pairs, n_pairs, g11, g12, g21, g22, ks, *, n_pairs_max=None, want_hist=False):
     """Raw shared-neighbour scores (int32 [n_pairs_max]) of the first ``n_pairs`` rows of ``pairs``."""
     lib = require_gpu()
-    device = pairs.device
+    device = _cuda_device(pairs, "pairs")
+    _cuda_device(n_pairs, "n_pairs")
     widths = {int(g.shape[1]) for g in (g11, g12, g21, g22)}
     if len(widths) != 1:  # differing widths: cut every table to its first ks columns
         g11, g12, g21, g22 = (g[:, :ks] for g in (g11, g12, g21, g22))
@@ -228,7 +239,9 @@ def anchor_filter(pairs, n_pairs, raw_score, p_lo, p_hi, codes1, codes2, *, thre
                   n_pairs_max=None, want_all_scores=False):
     """Normalised score + label filter with ordered compaction (device)."""
     lib = require_gpu()
-    device = pairs.device
+    device = _cuda_device(pairs, "pairs")
+    _cuda_device(n_pairs, "n_pairs")
+    _cuda_device(raw_score, "raw_score")
     codes1 = _dev_i32(codes1, device)
     codes2 = _dev_i32(codes2, device)
     if n_pairs_max is None:
@@ -253,7 +266,7 @@ def anchor_filter(pairs, n_pairs, raw_score, p_lo, p_hi, codes1, codes2, *, thre
 
 
 def knn_diag(n, m, d, k, splits=0, device=None):
-    """Per-wave counters of the last fused kernel (needs SCMIAC_FUSED_DIAG=1 at search time):
+    """Per-wave counters of the last fused kernel (needs ``set_tuning(diag=True)`` at search time):
     int64 array [waves, 12]."""
     off, nbytes, waves = ctypes.c_size_t(0), ctypes.c_size_t(0), ctypes.c_int(0)
     _check(load_library().scmiac_knn_diag_region(n, m, d, k, splits, ctypes.byref(off), ctypes.byref(nbytes),
@@ -270,6 +283,19 @@ def knn_grid_plan(n, m, d, k, splits=0):
     names = ("query_blocks", "queries_per_block", "S", "chunk_rows", "main_query_blocks", "St",
              "tail_chunk_rows", "grid_blocks")
     return dict(zip(names, (int(v) for v in plan)))
+
+
+def set_tuning(*, slots=0, tail_min_rows=0, no_tail=False, ablate=0, diag=False, variant=None):
+    """Diagnostic / tuning knobs of the fused kernel's grid plan (``set_tuning()`` resets them).
+    ``variant`` is ``"NWxRTxPCAPxGP"`` or a 4-tuple; an uncompiled one raises ``ValueError``."""
+    nw = rt = pcap = gp = 0
+    if variant:
+        parts = [int(v) for v in variant.split("x")] if isinstance(variant, str) else [int(v) for v in variant]
+        nw, rt = parts[0], parts[1]
+        pcap = parts[2] if len(parts) > 2 else 32
+        gp = parts[3] if len(parts) > 3 else 0
+    _check(load_library().scmiac_knn_set_tuning(int(slots), int(tail_min_rows), int(bool(no_tail)), int(ablate),
+                                                int(bool(diag)), nw, rt, pcap, gp))
 
 
 def set_timing(enabled: bool):
@@ -317,7 +343,8 @@ def ntxent2_forward(zi, zj, temperature):
     Returns ``(loss_parts, lse_row, lse_col)``: the loss is ``loss_parts.sum()``; the
     two log-sum-exp vectors are what :func:`ntxent2_backward` needs."""
     lib = require_gpu()
-    device = zi.device
+    device = _cuda_device(zi, "zi")
+    _cuda_device(zj, "zj")
     zi, zj = _dev_f32(zi, device), _dev_f32(zj, device)
     if zi.ndim != 2 or zi.shape != zj.shape:
         raise ValueError("zi and zj must be 2-D tensors of the same shape")
@@ -335,7 +362,9 @@ def ntxent2_forward(zi, zj, temperature):
 def ntxent2_backward(zi, zj, temperature, lse_row, lse_col, grad_out):
     """Gradients of the loss with respect to ``zi`` and ``zj`` (``grad_out``: one float32 on the device)."""
     lib = require_gpu()
-    device = zi.device
+    device = _cuda_device(zi, "zi")
+    for name, t in (("zj", zj), ("lse_row", lse_row), ("lse_col", lse_col)):
+        _cuda_device(t, name)
     zi, zj = _dev_f32(zi, device), _dev_f32(zj, device)
     grad_out = _dev_f32(grad_out, device).reshape(1)
     batch, d = zi.shape
@@ -352,7 +381,7 @@ def closer_count(q, r, match=None):
     """``counts[i] = #{j : D(q_i, r_j) < D(q_i, r_match(i))}`` as an int64 device tensor
     (``match=None``: row ``i`` of ``r``).  Raises ``IndexError`` for a match index outside ``r``."""
     lib = require_gpu()
-    device = q.device
+    device = _cuda_device(q, "q")
     q, r = _dev_f32(q, device), _dev_f32(r, device)
     if q.ndim != 2 or r.ndim != 2 or q.shape[1] != r.shape[1]:
         raise ValueError("q and r must be 2-D with the same number of columns")

@@ -5,6 +5,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "../../include/scmiac_hip.h"
 #include "kernels.h"
 
@@ -75,7 +77,9 @@ static int check_knn_args(int64_t n, int64_t m, int d, int k) {
 }
 
 // optional timing of the fused kernel: one event pair per search since timing was enabled
+// (g_timing_mu guards all of it: host threads may search concurrently)
 static constexpr int kMaxTimed = 256;
+static std::mutex g_timing_mu;
 static bool g_timing = false;
 static hipEvent_t g_ev0[kMaxTimed], g_ev1[kMaxTimed];
 static int g_ev_created = 0;
@@ -144,22 +148,23 @@ int scmiac_knn_search(const float* q, int64_t n, const float* r, int64_t m, int 
     HIP_TRY(hipMemsetAsync(n_uncertified, 0, sizeof(int32_t), stream), "memset n_uncertified");
     HIP_TRY(launch_pack(q, n, d, g, -2.0f, w.qp, g.rowf, nullptr, g.n_pad, w.maxnorm, stream), "pack queries");
     HIP_TRY(launch_pack(r, m, d, g, 1.0f, w.rp, g.ls, w.rnorm, g.m_pad, w.maxnorm, stream), "pack references");
-    const bool timed = g_timing && g_ev_used < kMaxTimed;
-    if (timed) {
-        if (g_ev_used >= g_ev_created) {
-            HIP_TRY(hipEventCreate(&g_ev0[g_ev_created]), "event create");
-            HIP_TRY(hipEventCreate(&g_ev1[g_ev_created]), "event create");
-            ++g_ev_created;
+    int slot = -1;  // event pair of this search, when timing is on
+    {
+        std::lock_guard<std::mutex> lock(g_timing_mu);
+        if (g_timing && g_ev_used < kMaxTimed) {
+            if (g_ev_used >= g_ev_created) {
+                HIP_TRY(hipEventCreate(&g_ev0[g_ev_created]), "event create");
+                HIP_TRY(hipEventCreate(&g_ev1[g_ev_created]), "event create");
+                ++g_ev_created;
+            }
+            slot = g_ev_used++;
         }
-        HIP_TRY(hipEventRecord(g_ev0[g_ev_used], stream), "event record");
     }
-    const char* dg = getenv("SCMIAC_FUSED_DIAG");  // diagnostic runs: per-wave cycle counters
-    HIP_TRY(launch_fused(g, w.qp, w.rp, w.rnorm, w.lists, w.pend, n, knn_threshold_rank(k), (dg && dg[0] == '1') ? w.diag : nullptr, stream),
+    if (slot >= 0) HIP_TRY(hipEventRecord(g_ev0[slot], stream), "event record");
+    const bool diag = knn_get_tuning().diag != 0;  // diagnostic runs: per-wave cycle counters
+    HIP_TRY(launch_fused(g, w.qp, w.rp, w.rnorm, w.lists, w.pend, n, knn_threshold_rank(k), diag ? w.diag : nullptr, stream),
             "fused distance + top-k");
-    if (timed) {
-        HIP_TRY(hipEventRecord(g_ev1[g_ev_used], stream), "event record");
-        ++g_ev_used;
-    }
+    if (slot >= 0) HIP_TRY(hipEventRecord(g_ev1[slot], stream), "event record");
     HIP_TRY(launch_refine(q, w.qp, w.rp, d, n, g, w.lists, k, knn_threshold_rank(k), col_offset, merge, w.maxnorm, idx, dist2, dist,
                           lower_bound, uncertified_rows, n_uncertified, stream),
             "refine");
@@ -252,13 +257,27 @@ int scmiac_anchor_filter(const int64_t* pairs, const int64_t* n_pairs, int64_t n
 }
 
 int scmiac_knn_set_timing(int enabled) {
+    std::lock_guard<std::mutex> lock(g_timing_mu);
     g_timing = enabled != 0;
     g_ev_used = 0;
     return SCMIAC_OK;
 }
 
+int scmiac_knn_set_tuning(int slots, int tail_min_rows, int no_tail, int ablate, int diag, int nw, int rt, int pcap,
+                          int gp) {
+    FusedTuning t{};
+    t.slots = slots; t.tail_min_rows = tail_min_rows; t.no_tail = no_tail; t.ablate = ablate; t.diag = diag;
+    t.has_variant = (nw > 0 || rt > 0) ? 1 : 0;
+    t.nw = nw; t.rt = rt; t.pcap = pcap; t.gp = gp;
+    if (!knn_set_tuning(t))
+        return fail(SCMIAC_ERR_ARG, "tuning rejected: negative value, or kernel variant %dx%dx%dx%d is not compiled",
+                    nw, rt, pcap, gp);
+    return SCMIAC_OK;
+}
+
 int scmiac_knn_fused_ms(float* total_ms, int* launches) {
     if (!total_ms || !launches) return fail(SCMIAC_ERR_ARG, "NULL output pointer");
+    std::lock_guard<std::mutex> lock(g_timing_mu);
     float sum = 0.f;
     for (int i = 0; i < g_ev_used; ++i) {
         float ms = 0.f;

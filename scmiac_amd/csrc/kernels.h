@@ -44,6 +44,19 @@ struct KnnGeometry {
     int blocks;            // grid size of the fused kernel
 };
 
+// Diagnostic / tuning knobs of the fused kernel's grid plan (all zero = product behaviour).
+struct FusedTuning {
+    int slots;          // > 0: pretend the GPU runs this many blocks at once
+    int tail_min_rows;  // > 0: shortest reference chunk the planner may choose
+    int no_tail;        // 1: never split the last round's query blocks further
+    int ablate;         // ablation bits of the diagnostic kernel instantiation
+    int diag;           // 1: per-wave cycle counters into the workspace
+    int has_variant;    // 1: use (nw, rt, pcap, gp) where that combination is compiled
+    int nw, rt, pcap, gp;
+};
+FusedTuning knn_get_tuning();
+bool knn_set_tuning(const FusedTuning& t);  // false: rejected (uncompiled variant, negative value)
+
 int knn_pick_d2(int d);
 // rank of the shortlist entry whose key serves as the running threshold: the k wanted
 // neighbours plus a margin that the rounding-error certificate can absorb

@@ -19,6 +19,7 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <mutex>
 #include <type_traits>
 
 #include "kernels.h"
@@ -683,8 +684,33 @@ static hipError_t launch_fused_t(const float* Qp, const float* Rp, const float* 
     return hipGetLastError();
 }
 
+// Diagnostic / tuning state (set through scmiac_knn_set_tuning only; all zero in normal use).
+// One mutex guards it together with the occupancy cache below: host threads may search
+// concurrently.
+static std::mutex g_plan_mu;
+static FusedTuning g_tuning{};
+
+static bool fused_variant_compiled(int D2, int nw, int rt, int pcap, int gp);
+
+FusedTuning knn_get_tuning() {
+    std::lock_guard<std::mutex> lock(g_plan_mu);
+    return g_tuning;
+}
+
+bool knn_set_tuning(const FusedTuning& t) {
+    if (t.has_variant) {  // must be a compiled combination for at least one feature size
+        bool any = false;
+        for (int v : kD2Sizes) any = any || fused_variant_compiled(v, t.nw, t.rt, t.pcap, t.gp);
+        if (!any) return false;
+    }
+    if (t.slots < 0 || t.tail_min_rows < 0 || t.ablate < 0) return false;
+    std::lock_guard<std::mutex> lock(g_plan_mu);
+    g_tuning = t;
+    return true;
+}
+
 // (waves per block, reference rows per LDS stage) of the fused kernel
-static void fused_variant(int D2, int* nw, int* rt, int* pcap, int* gp) {
+static void fused_variant(int D2, const FusedTuning& tn, int* nw, int* rt, int* pcap, int* gp) {
     // 12 waves per block (3 per SIMD) wherever the registers allow (up to 100 features), the
     // pending-candidate buffers in global memory and all of the LDS given to two stages as
     // long as it holds: 320 rows up to 50 features, 256 up to 64, 128 up to 128, 64 beyond
@@ -693,11 +719,9 @@ static void fused_variant(int D2, int* nw, int* rt, int* pcap, int* gp) {
     *rt = (D2 <= 25) ? 320 : (D2 <= 32) ? 256 : (D2 <= 64) ? 128 : 64;
     *pcap = 64;  // 64 pending candidates per query: half as many merges as with 32
     *gp = 1;
-    if (const char* v = getenv("SCMIAC_FUSED_VARIANT")) {  // tuning aid: "NWxRTxPCAPxGP", e.g. 12x256x32x1
-        int a = 0, b = 0, c = 32, e = 0;
-        if (sscanf(v, "%dx%dx%dx%d", &a, &b, &c, &e) >= 2) {  // (the combination must be a compiled one)
-            *nw = a; *rt = b; *pcap = c; *gp = e;
-        }
+    // tuning aid: another compiled combination for this feature size, when there is one
+    if (tn.has_variant && fused_variant_compiled(D2, tn.nw, tn.rt, tn.pcap, tn.gp)) {
+        *nw = tn.nw; *rt = tn.rt; *pcap = tn.pcap; *gp = tn.gp;
     }
 }
 
@@ -721,9 +745,17 @@ static int fused_occupancy_t() {
     }
     return cus * per_cu;
 }
+static bool fused_variant_compiled(int D2, int nw, int rt, int pcap, int gp) {
+#define SCMIAC_HAS_CASE(V_, NW_, RT_, PC_, GP_) \
+    if (D2 == V_ && nw == NW_ && rt == RT_ && pcap == PC_ && gp == GP_) return true;
+    SCMIAC_FUSED_VARIANTS(SCMIAC_HAS_CASE)
+#undef SCMIAC_HAS_CASE
+    return false;
+}
 static int fused_concurrent_blocks(const KnnGeometry& g) {
     static int cache[32][2];  // variant -> slots; a handful of variants exist
     static int n_cached = 0;
+    std::lock_guard<std::mutex> lock(g_plan_mu);
     const int tag = (((g.D2 * 100 + g.nw) * 1000 + g.RT) * 100 + g.pcap) * 2 + g.gp;
     for (int i = 0; i < n_cached; ++i)
         if (cache[i][0] == tag) return cache[i][1];
@@ -744,7 +776,8 @@ KnnGeometry knn_geometry(long long n, long long m, int d, int k, int splits) {
     g.D2P = (g.D2 + 3) & ~3;
     g.rowf = 2 * g.D2P;
     g.ls = g.rowf + (((g.rowf / 4) % 2 == 0) ? 4 : 8);
-    fused_variant(g.D2, &g.nw, &g.RT, &g.pcap, &g.gp);
+    const FusedTuning tn = knn_get_tuning();
+    fused_variant(g.D2, tn, &g.nw, &g.RT, &g.pcap, &g.gp);
     g.qpb = g.nw * 32;
     g.n_pad = ((n + g.qpb - 1) / g.qpb) * g.qpb;
     g.nqb = (int)(g.n_pad / g.qpb);
@@ -753,9 +786,9 @@ KnnGeometry knn_geometry(long long n, long long m, int d, int k, int splits) {
     long long min_chunk = 8192;  // shortest reference chunk considered
     // test aids: pretend the GPU runs fewer blocks at once / allow short chunks, so that
     // small problems exercise every region of the grid
-    if (const char* v = getenv("SCMIAC_FUSED_SLOTS")) { int a = atoi(v); if (a > 0) slots = a; }
-    if (const char* v = getenv("SCMIAC_FUSED_TAIL_MIN_ROWS")) { int a = atoi(v); if (a > 0) min_chunk = a; }
-    const char* no_tail = getenv("SCMIAC_FUSED_NO_TAIL");  // tuning aid
+    if (tn.slots > 0) slots = tn.slots;
+    if (tn.tail_min_rows > 0) min_chunk = tn.tail_min_rows;
+    const bool no_tail = tn.no_tail != 0;  // tuning aid
 
     // Grid plan.  Query blocks [0, qb0) ("main") are searched in S reference chunks each,
     // qb0 * S being a whole number of rounds of `slots` concurrent blocks; the remaining
@@ -787,7 +820,7 @@ KnnGeometry knn_geometry(long long n, long long m, int d, int k, int splits) {
             while (b) { int tmp = gcd % b; gcd = b; b = tmp; }
             const int step = slots / gcd;  // main query blocks come in multiples of this
             int q0 = (g.nqb / step) * step;
-            if (no_tail && no_tail[0] == '1') q0 = g.nqb;
+            if (no_tail) q0 = g.nqb;
             const double chunk_s = (double)m / s;
             const double main_cost = (double)((long long)q0 * s / slots) * block_cycles(chunk_s);
             const int tail_blocks = g.nqb - q0;
@@ -838,11 +871,10 @@ hipError_t launch_fused(const KnnGeometry& g, const float* Qp, const float* Rp, 
                         unsigned long long* lists, void* pend_g_, long long n, int kt,
                         unsigned long long* diag, hipStream_t stream) {
     uint2* pend_g = static_cast<uint2*>(pend_g_);
-    // counters (diag) and ablations (SCMIAC_FUSED_ABLATE bits: 1 no selection, 2 no staging,
-    // 4 no barrier, 8 empty candidate path, 16 candidate arithmetic only) live in a separate
-    // instantiation of the kernel; the product kernel carries neither
-    int ablate = 0;
-    if (const char* v = getenv("SCMIAC_FUSED_ABLATE")) ablate = atoi(v);
+    // counters (diag) and ablations (tuning bits: 1 no selection, 2 no staging, 4 no barrier,
+    // 8 empty candidate path, 16 candidate arithmetic only) live in a separate instantiation
+    // of the kernel; the product kernel carries neither
+    const int ablate = knn_get_tuning().ablate;
 #define SCMIAC_FUSED_CASE(V_, NW_, RT_, PC_, GP_)                                                  \
     if (g.D2 == V_ && g.nw == NW_ && g.RT == RT_ && g.pcap == PC_ && g.gp == GP_)                  \
         return (diag || ablate) ? launch_fused_t<V_, NW_, RT_, PC_, (GP_ != 0), true>(Qp, Rp, rnorm, lists, pend_g, n, g.n_pad, g.nqb, g.S, g.chunk_rows, g.tail, kt, ablate, diag, stream) \

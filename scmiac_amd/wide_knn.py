@@ -54,7 +54,10 @@ def knn_search_wide(q, r, k, *, n_groups=None, query_chunk=32768):
         top = torch.sort(keys, dim=1).values[:, :k]
         kth = top[:, k - 1:k]
         last = keys[:, _hip.KNN_MAX_K - 1::_hip.KNN_MAX_K]     # 64th key of every group
-        cut_short = ((last != _SENTINEL) & (last < kth)).any(dim=1)
+        # only a group of more than 64 rows can have rows it did not list: a group of exactly
+        # 64 also ends in a real key, but its list is the whole group
+        may_cut = torch.tensor([g.shape[0] > _hip.KNN_MAX_K for g in groups], device=device)
+        cut_short = ((last != _SENTINEL) & (last < kth) & may_cut).any(dim=1)
         idx[c0:c0 + qc.shape[0]] = (top & 0xFFFFFFFF).to(torch.int32)
         d2[c0:c0 + qc.shape[0]] = (top >> 32).to(torch.int32).view(torch.float32)
         bad = torch.nonzero(cut_short).flatten()

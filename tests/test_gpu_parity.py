@@ -135,11 +135,19 @@ def test_knn_exact_rows_scratch_modes(scratch_rows):
     np.testing.assert_array_equal(st.dist2.cpu().numpy(), d2_o)
 
 
-def test_knn_tail_region(monkeypatch):
+@pytest.fixture
+def tuning():
+    """Tuning knobs of the fused kernel, reset after the test."""
+    try:
+        yield _hip.set_tuning
+    finally:
+        _hip.set_tuning()
+
+
+def test_knn_tail_region(tuning):
     """The query blocks of the grid's last round search the references in several
     chunks each.  Forced at a small size by pretending the GPU runs 8 blocks at once."""
-    monkeypatch.setenv("SCMIAC_FUSED_SLOTS", "8")
-    monkeypatch.setenv("SCMIAC_FUSED_TAIL_MIN_ROWS", "1024")
+    tuning(slots=8, tail_min_rows=1024)
     Q = _mixture(61, 5000, 50)              # 14 query blocks of 384: 8 + a tail of 6
     R = _mixture(62, 20000, 50, offset=True)
     R[5000:5100] = R[3]                      # ties across tail chunks -> direct evaluation too
@@ -423,10 +431,10 @@ def test_ring_search_unit_norm_d64_single_rank(tmp_path):
 
 
 @pytest.mark.parametrize("variant", ["12x256x16x1", "12x128x32x0", "12x128x32x1"])
-def test_knn_kernel_variants_agree_with_oracle(monkeypatch, variant):
+def test_knn_kernel_variants_agree_with_oracle(tuning, variant):
     """Other compiled shapes of the fused kernel (short pending buffers that refill within
     one subtile, buffers in LDS, 128-row stages) give the same exact result."""
-    monkeypatch.setenv("SCMIAC_FUSED_VARIANT", variant)
+    tuning(variant=variant)
     Q = _mixture(81, 1500, 50)
     R = _mixture(82, 12000, 50, offset=True)
     Q[:40] = R[:40]  # queries sitting on references: many small scores early in the stream

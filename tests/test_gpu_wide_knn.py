@@ -40,6 +40,20 @@ def test_wide_knn_cut_short_groups_are_searched_again():
         knn_search_wide(torch.from_numpy(q).cuda(), torch.from_numpy(r[:50]).cuda(), 60 + 4)
 
 
+def test_wide_knn_groups_of_exactly_64_rows_are_complete():
+    """Groups of exactly 64 rows end in a real 64th key, but their lists are the whole group:
+    a list that ends before the k-th merged key is then no sign of a row left out."""
+    rng = np.random.default_rng(21)
+    n_groups, d = 8, 12
+    m = 64 * n_groups
+    # rows dealt round-robin: group g holds rows g, g + 8, ...; put group 0 entirely near the queries
+    r = (rng.normal(size=(m, d)) + 20.0).astype(np.float32)
+    r[0::n_groups] = rng.normal(size=(64, d)).astype(np.float32) * 0.1
+    q = rng.normal(size=(30, d)).astype(np.float32) * 0.1
+    _check(q, r, 100, n_groups=n_groups)     # group 0's 64 rows all rank before the 100th key
+    _check(q, r[:2 * 64], 70, n_groups=2)    # reached by the regrouping of a two-group search as well
+
+
 def test_index_object_serves_wide_queries():
     rng = np.random.default_rng(8)
     data = rng.normal(size=(3000, 30)).astype(np.float32)

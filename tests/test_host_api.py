@@ -125,7 +125,56 @@ def test_grid_plan(monkeypatch):
     p = _hip.knn_grid_plan(3000, 20000, 50, 30, splits=7)
     assert p["S"] == 7 and p["main_query_blocks"] == 8 and p["grid_blocks"] == 56
     # test aid: a pretend 8-slot GPU makes small problems grow a tail
+    _hip.set_tuning(slots=8, tail_min_rows=1024)
+    try:
+        p = _hip.knn_grid_plan(3300, 20000, 50, 30)   # 9 query blocks: 8 + a tail of 1
+        assert p["main_query_blocks"] == 8 and p["St"] > 1 and p["grid_blocks"] == 8 + p["St"]
+    finally:
+        _hip.set_tuning()
+    # the library reads no environment variables: a variable of that name changes nothing
     monkeypatch.setenv("SCMIAC_FUSED_SLOTS", "8")
-    monkeypatch.setenv("SCMIAC_FUSED_TAIL_MIN_ROWS", "1024")
-    p = _hip.knn_grid_plan(3300, 20000, 50, 30)   # 9 query blocks: 8 + a tail of 1
-    assert p["main_query_blocks"] == 8 and p["St"] > 1 and p["grid_blocks"] == 8 + p["St"]
+    assert _hip.knn_grid_plan(3300, 20000, 50, 30)["main_query_blocks"] != 8
+    # a kernel variant that is not compiled is rejected, not silently launched
+    with pytest.raises(ValueError):
+        _hip.set_tuning(variant="7x100x32x1")
+    with pytest.raises(ValueError):
+        _hip.set_tuning(slots=-1)
+
+
+def test_host_tensors_are_rejected_before_any_launch(monkeypatch):
+    """The kernels take device pointers: a tensor in host memory must raise in Python, with
+    no call into the library (the reference's losses and metrics accept CPU tensors)."""
+    import torch
+
+    from scmiac_amd import _hip
+
+    calls = []
+
+    class _Recorder:
+        def __getattr__(self, name):
+            def fn(*a):
+                calls.append(name)
+                return 0
+            return fn
+
+    monkeypatch.setattr(_hip, "require_gpu", lambda: _Recorder())
+    z = torch.randn(8, 4)
+    i32 = torch.zeros((8, 4), dtype=torch.int32)
+    pairs = torch.zeros((8, 2), dtype=torch.int64)
+    one = torch.zeros(1, dtype=torch.int64)
+    cases = [
+        lambda: _hip.ntxent2_forward(z, z, 0.5),
+        lambda: _hip.ntxent2_backward(z, z, 0.5, z[:, 0], z[:, 0], torch.ones(1)),
+        lambda: _hip.closer_count(z, z),
+        lambda: _hip.find_mnn(i32, i32, 2),
+        lambda: _hip.snn_score(pairs, one, i32, i32, i32, i32, 3),
+        lambda: _hip.anchor_filter(pairs, one, i32[:, 0], 0.0, 1.0, i32[:, 0], i32[:, 0]),
+    ]
+    for case in cases:
+        with pytest.raises(ValueError, match="GPU device"):
+            case()
+    assert calls == []
+    from scmiac_amd.modeling.loss import NTXentLoss2
+    with pytest.raises(ValueError, match="GPU device"):
+        NTXentLoss2(0.5)(z, z)
+    assert calls == []

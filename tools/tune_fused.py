@@ -32,19 +32,20 @@ def main():
     q, r = torch.from_numpy(U).cuda(), torch.from_numpy(V).cuda()
     res = {v: [] for v in args.variants}
     ref_idx = None
+    # the library reads no environment: this tool turns its own variables into tuning calls
+    ablate = int(os.environ.get("SCMIAC_FUSED_ABLATE", "0"))
+    diag = os.environ.get("SCMIAC_FUSED_DIAG") == "1"
+    no_tail = os.environ.get("SCMIAC_FUSED_NO_TAIL") == "1"
     for rnd in range(args.rounds + 1):
         for v in args.variants:
-            if v == "default":
-                os.environ.pop("SCMIAC_FUSED_VARIANT", None)
-            else:
-                os.environ["SCMIAC_FUSED_VARIANT"] = v
+            _hip.set_tuning(variant=None if v == "default" else v, ablate=ablate, diag=diag, no_tail=no_tail)
             _hip.set_timing(True)
             # ablated kernels leave poor shortlists: skip the direct-evaluation pass they would trigger
-            ablated = os.environ.get("SCMIAC_FUSED_ABLATE", "0") != "0"
+            ablated = ablate != 0
             st = _hip.knn_search(q, r, args.k, splits=args.splits, exact_fallback=not ablated)
             ms, cnt = _hip.fused_ms()
             _hip.set_timing(False)
-            if os.environ.get("SCMIAC_FUSED_ABLATE", "0") != "0":
+            if ablated:
                 pass
             elif ref_idx is None:
                 ref_idx = st.idx.clone()
@@ -52,7 +53,7 @@ def main():
                 print(f"variant {v}: RESULT DIFFERS from the first variant", flush=True)
             if rnd > 0:
                 res[v].append(ms)
-    if os.environ.get("SCMIAC_FUSED_DIAG") == "1":
+    if diag:
         dg = _hip.knn_diag(args.n, args.m, d, args.k, args.splits).astype(np.float64)
         tot = dg[:, 0]
         print(f"diag ({args.variants[-1]}): waves {len(dg)}  wave cycles mean {tot.mean():.3e}  "
