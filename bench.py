@@ -4,6 +4,7 @@ search (one cross-modal k-NN table: N RNA query cells against M ATAC reference
 cells), on synthetic Gaussian-mixture latents resident in HBM.
 
     python bench.py --gpus 1 --steps K --warmup W             (one MI355X)
+    python bench.py --gpus N ...            (starts N ranks itself, one per GPU, as a child torchrun)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 One step = one whole table: pack both sets, fused fp32-MFMA distance + top-k,
@@ -25,8 +26,12 @@ Rank 0 prints one JSON line.  Next to the headline it carries
 from __future__ import annotations
 
 import argparse
+import hashlib
+import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -77,6 +82,65 @@ def make_latents(name, n=None, m=None):
     return U, V, l1.astype(np.int32), l2.astype(np.int32), d
 
 
+def spawn_ranks(n_ranks):
+    """Start this script once per GPU under torch.distributed.run and return the launcher's
+    exit status.  A child process, never an exec, and nothing here has touched the GPU yet."""
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           "--",  # what follows is the script and its own options, whatever they look like to the launcher
+           str(Path(__file__).resolve())] + sys.argv[1:]
+    return subprocess.run(cmd).returncode
+
+
+class _NoComputeBackend:
+    """``--dry-launch`` without an injected backend: the launch plumbing (ranks, shards, gather,
+    timing, JSON) runs, the search itself is replaced by a table of reference row 0."""
+
+    @staticmethod
+    def knn_search(q, r, k, **_):
+        st = _hip.KnnState(q.shape[0], k, q.device)
+        st.idx.zero_()
+        st.dist2.zero_()
+        return st
+
+
+def _dry_backend():
+    spec = os.environ.get("SCMIAC_BENCH_DRY_BACKEND")  # "module:attribute", injected by the CPU tests
+    if not spec:
+        return _NoComputeBackend()
+    mod, attr = spec.split(":")
+    return getattr(importlib.import_module(mod), attr)()
+
+
+def stored_traffic(workload, n_local, kernel_name):
+    """HBM bytes per launch of the fused kernel from a stored counter profile -- only when that
+    profile was taken on this workload, this launch's kernel instantiation and these kernel
+    sources; ``(None, reason)`` otherwise.  It is never measured in the bench run itself."""
+    tfile = ROOT / "profiles" / "fused_knn_hbm_traffic.json"
+    try:
+        rec = json.loads(tfile.read_text())
+    except Exception:
+        return None, "no stored counter profile"
+    if rec.get("workload") != workload or rec.get("n_local") != n_local:
+        return None, "stored profile is of another workload"
+    if rec.get("kernel", "").replace("scmiac::", "") != kernel_name:
+        return None, f"stored profile is of {rec.get('kernel')}, this run launched {kernel_name}"
+    if rec.get("source_sha256") != kernel_source_hash():
+        return None, "kernel sources changed since the stored profile was taken"
+    return rec.get("hbm_bytes_per_launch"), (f"stored rocprofv3 --pmc profile {tfile.relative_to(ROOT)} "
+                                             f"({rec.get('kernel')}), not measured in this run")
+
+
+def kernel_source_hash():
+    h = hashlib.sha256()
+    for name in ("knn_kernels.hip", "fused_common.h", "kernels.h"):
+        h.update((ROOT / "scmiac_amd" / "csrc" / name).read_bytes())
+    return h.hexdigest()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -89,21 +153,41 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU baseline sample (0 = auto: about 15 s of CPU work)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline / parity sample")
     ap.add_argument("--no-full", action="store_true", help="skip the full four-table anchor search timing")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="rehearse the N-rank launch without GPUs: gloo on the CPU, the search replaced by a "
+                         "stand-in; the JSON line is marked dry_launch and carries no throughput claim")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+
+    # `python bench.py --gpus N` with no launcher around it: become the launcher.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}: one rank per GPU is the contract")
     # SCMIAC_BENCH_FORCE_DIST=1 runs the multi-rank code path (process group, gather) with a
     # single rank: a rehearsal of the N > 1 launch on a one-GPU box
     distributed = world > 1 or os.environ.get("SCMIAC_BENCH_FORCE_DIST") == "1"
-    if distributed and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dry = args.dry_launch
+    if dry:
+        dev = torch.device("cpu")
+        backend = _dry_backend()
+    else:
+        if torch.cuda.device_count() <= local_rank:
+            raise SystemExit(f"rank {rank}: GPU {local_rank} does not exist ({torch.cuda.device_count()} visible)")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        backend = _hip
     if distributed:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if dry:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     U, V, l1, l2, d = make_latents(args.workload, args.n, args.m)
     n, m, k = U.shape[0], V.shape[0], args.k
@@ -113,7 +197,7 @@ def main():
     r_dev = torch.from_numpy(V).to(dev)
 
     def step():
-        st = sharded.knn_replicated(q_dev, r_dev, k)
+        st = sharded.knn_replicated(q_dev, r_dev, k, backend=backend)
         if distributed:
             st.gathered = sharded.gather_rows(st.idx, n)  # every rank ends up with the whole table
         return st
@@ -121,19 +205,22 @@ def main():
     def fence():
         if distributed:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        if not dry:
+            torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
         step()
-    _hip.set_timing(True)  # HIP events around every fused-kernel launch of the timed region
+    if not dry:
+        _hip.set_timing(True)  # HIP events around every fused-kernel launch of the timed region
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         st = step()
     fence()
     elapsed = time.perf_counter() - t0
-    fused_total_ms, fused_launches = _hip.fused_ms()
-    _hip.set_timing(False)
+    fused_total_ms, fused_launches = (0.0, 0) if dry else _hip.fused_ms()
+    if not dry:
+        _hip.set_timing(False)
 
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -144,20 +231,17 @@ def main():
 
     n_local = hi - lo
     flops = 2.0 * n_local * m * d
-    fused_avg_ms = fused_total_ms / max(fused_launches, 1)
-    achieved = flops / (fused_avg_ms * 1e-3) / 1e12
-    traffic = None
-    tfile = ROOT / "profiles" / "fused_knn_hbm_traffic.json"
-    if tfile.exists():
-        try:
-            rec = json.loads(tfile.read_text())
-            if rec.get("workload") == args.workload and rec.get("n_local") == n_local:
-                traffic = rec.get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-    roofline = {"bound": "mfma", "kernel": "fused_knn_kernel", "achieved": round(achieved, 2),
-                "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-                "traffic": traffic, "kernel_ms": round(fused_avg_ms, 3), "flops_per_launch": flops}
+    if dry:
+        roofline = None
+    else:
+        fused_avg_ms = fused_total_ms / max(fused_launches, 1)
+        achieved = flops / (fused_avg_ms * 1e-3) / 1e12
+        kernel_name = _hip.knn_kernel_name(n_local, m, d, k)
+        traffic, traffic_source = stored_traffic(args.workload if not (args.n or args.m) else None, n_local, kernel_name)
+        roofline = {"bound": "mfma", "kernel": kernel_name, "achieved": round(achieved, 2),
+                    "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                    "traffic": traffic, "traffic_source": traffic_source,
+                    "kernel_ms": round(fused_avg_ms, 3), "flops_per_launch": flops}
 
     out = {
         "metric": "anchor-search query cells/sec (N=M=1M, d=50, k=30)" if args.workload == "c3" and not (args.n or args.m)
@@ -171,17 +255,21 @@ def main():
                    "uncertified_rows_last_step": int(st.n_uncertified.item())},
         "roofline": roofline,
     }
+    if dry:
+        out.update(dry_launch=True, value=None, ms_per_step=None, data="none (launch rehearsal on the CPU)")
+        out["config"]["backend"] = type(backend).__name__
+        out["config"]["table_checksum"] = int(st.gathered.to(torch.int64).sum()) if distributed else int(st.idx.to(torch.int64).sum())
 
     if distributed:  # the gathered table is the shards' tables in rank order
         assert torch.equal(st.gathered[lo:hi], st.idx)
 
-    if rank == 0 and not distributed and not args.no_full:
+    if rank == 0 and not distributed and not args.no_full and not dry:
         out["pcie_inclusive"] = pcie_inclusive(U, V, k, dev)
 
-    if rank == 0 and not args.no_cpu:
+    if rank == 0 and not args.no_cpu and not dry:
         out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(U[lo:hi], V, k, st, args.cpu_rows)
 
-    if rank == 0 and not args.no_full and not distributed:
+    if rank == 0 and not args.no_full and not distributed and not dry:
         out["full_search"] = full_search(U, V, l1, l2, k, dev)
 
     if distributed:

@@ -197,6 +197,15 @@ SCMIAC_API int scmiac_knn_diag_region(int64_t n, int64_t m, int d, int k, int sp
 SCMIAC_API int scmiac_knn_grid_plan(int64_t n, int64_t m, int d, int k, int splits, int64_t *plan);
 
 /*
+ * Name of the fused kernel instantiation scmiac_knn_search would launch for this problem,
+ * as a profiler prints it without the namespace, e.g.
+ * "fused_knn_kernel<25, 12, 320, 64, true, false>" (no counterpart in the reference; no GPU
+ * work).  Lets a measurement say which compiled variant it timed.
+ */
+SCMIAC_API int scmiac_knn_kernel_name(int64_t n, int64_t m, int d, int k, int splits, char *buf,
+                                      size_t buf_bytes);
+
+/*
  * Optional in-library timing of the fused distance + top-k kernel (no counterpart
  * in the reference).  While enabled, every scmiac_knn_search brackets that kernel's
  * launch with a pair of HIP events on `stream` (up to 256 searches; enabling again

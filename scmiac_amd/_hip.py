@@ -40,6 +40,7 @@ _SIGNATURES = {
     "scmiac_knn_diag_region": ([_i64, _i64, _i32, _i32, _i32, _c.POINTER(_sz), _c.POINTER(_sz),
                                 _c.POINTER(_c.c_int)], _c.c_int),
     "scmiac_knn_grid_plan": ([_i64, _i64, _i32, _i32, _i32, _c.POINTER(_i64)], _c.c_int),
+    "scmiac_knn_kernel_name": ([_i64, _i64, _i32, _i32, _i32, _c.c_char_p, _sz], _c.c_int),
     "scmiac_knn_set_timing": ([_i32], _c.c_int),
     "scmiac_knn_set_tuning": ([_i32] * 9, _c.c_int),
     "scmiac_knn_fused_ms": ([_c.POINTER(_c.c_float), _c.POINTER(_c.c_int)], _c.c_int),
@@ -283,6 +284,13 @@ def knn_grid_plan(n, m, d, k, splits=0):
     names = ("query_blocks", "queries_per_block", "S", "chunk_rows", "main_query_blocks", "St",
              "tail_chunk_rows", "grid_blocks")
     return dict(zip(names, (int(v) for v in plan)))
+
+
+def knn_kernel_name(n, m, d, k, splits=0):
+    """Instantiation of the fused kernel a search of this shape launches (needs no GPU)."""
+    buf = ctypes.create_string_buffer(128)
+    _check(load_library().scmiac_knn_kernel_name(n, m, d, k, splits, buf, len(buf)))
+    return buf.value.decode()
 
 
 def set_tuning(*, slots=0, tail_min_rows=0, no_tail=False, ablate=0, diag=False, variant=None):

@@ -15,19 +15,22 @@ from pathlib import Path
 from typing import Sequence
 
 
-def require_argument(value, name: str) -> None:
-    if value is None:
-        raise SystemExit(f"Missing required argument: {name}. Provide it via CLI or YAML config.")
+MISSING = "Missing required argument: {flag}. Provide it via CLI or YAML config."  # reference wording (cli.py:32)
 
 
-def parse_hidden_dims(value: str) -> list:
-    parts = [item.strip() for item in value.split(",") if item.strip()]
-    if not parts:
-        raise argparse.ArgumentTypeError("hidden_dims must contain at least one integer")
-    try:
-        return [int(item) for item in parts]
-    except ValueError as exc:
-        raise argparse.ArgumentTypeError("hidden_dims must be a comma-separated list of integers") from exc
+def _demand(args, *dests):
+    """Stop with the reference's message for the first of ``dests`` the user left out."""
+    for dest in dests:
+        if getattr(args, dest) is None:
+            raise SystemExit(MISSING.format(flag="--" + dest.replace("_", "-")))
+
+
+def _layer_widths(text: str) -> list:
+    """``"128,64"`` -> ``[128, 64]``; blanks around and between the commas are ignored."""
+    fields = [f for f in (piece.strip() for piece in text.split(",")) if f]
+    if not fields or not all(f.lstrip("+-").isdigit() for f in fields):
+        raise argparse.ArgumentTypeError(f"expected integers separated by commas, got {text!r}")
+    return [int(f) for f in fields]
 
 
 def _read_h5ad(path):
@@ -48,9 +51,7 @@ def write_anchors(anchor_df, output_dir) -> Path:
 
 
 def run_train(args: argparse.Namespace) -> int:
-    require_argument(args.rna_h5ad, "--rna-h5ad")
-    require_argument(args.atac_h5ad, "--atac-h5ad")
-    require_argument(args.output_dir, "--output-dir")
+    _demand(args, "rna_h5ad", "atac_h5ad", "output_dir")
 
     from .modeling.scmiac import find_anchors
 
@@ -102,54 +103,64 @@ def _continue_with_reference(reference, args, adata_rna, adata_atac, anchor_df) 
     return 0
 
 
+# `scmiac train` options: (flag, default, type or None, what it is).  Names and defaults are the
+# reference's schema (cli.py:182-208); scripts written for it must keep working.
+_TRAIN_OPTIONS = (
+    ("--rna-h5ad", None, None, "h5ad file of the RNA cells"),
+    ("--atac-h5ad", None, None, "h5ad file of the ATAC cells"),
+    ("--output-dir", None, None, "where anchors.csv (and, with scMIAC installed, models and embeddings) go"),
+    ("--all-nfeatures", 3000, int, "genes kept for the CCA over both modalities"),
+    ("--single-nfeatures", 2000, int, "variable genes ranked per modality"),
+    ("--k-anchor", 5, int, "mutual-neighbour depth: a pair is an anchor if each cell is among the other's k nearest"),
+    ("--n-components", 30, int, "canonical components searched in"),
+    ("--rna-latent-key", "X_pca", None, "obsm key of the RNA input of the VAE"),
+    ("--atac-latent-key", "lsi49", None, "obsm key of the ATAC input of the VAE"),
+    ("--rna-celltype-key", "cell_type", None, "obs column with the RNA cell types"),
+    ("--atac-celltype-key", "pred", None, "obs column with the (predicted) ATAC cell types"),
+    ("--batch-size", 256, int, "cells per batch"),
+    ("--hidden-dims", [128, 64], _layer_widths, "encoder layer widths, e.g. 128,64"),
+    ("--latent-dim", 30, int, "width of the VAE latent space"),
+    ("--device", "cuda:0", None, "torch device of the training stages"),
+    ("--num-epochs", 2000, int, "epochs"),
+    ("--lambda-rna-kl", 1.0, float, "KL weight, RNA"),
+    ("--lambda-atac-kl", 1.0, float, "KL weight, ATAC"),
+    ("--alpha-rna-rec", 20.0, float, "reconstruction weight, RNA"),
+    ("--alpha-atac-rec", 20.0, float, "reconstruction weight, ATAC"),
+    ("--lambda-contra", 300.0, float, "weight of the contrastive anchor loss"),
+    ("--temperature", 0.5, float, "softmax temperature of the anchor loss"),
+    ("--learning-rate", 1e-3, float, "Adam step size"),
+    ("--print-step", 10, int, "epochs between log lines"),
+)
+
+
 def build_parser() -> argparse.ArgumentParser:
-    parser = argparse.ArgumentParser(
-        prog="scmiac",
-        description="scMIAC anchor search on MI355X (drop-in for the anchor stage of `scmiac train`)")
-    subparsers = parser.add_subparsers(dest="command", help="Available commands")
-    p = subparsers.add_parser("train", help="Generate cell-type-filtered MNN anchors (then train, if scMIAC is installed)")
-    p.add_argument("--rna-h5ad", default=None, help="Path to RNA AnnData file")
-    p.add_argument("--atac-h5ad", default=None, help="Path to ATAC AnnData file")
-    p.add_argument("--output-dir", default=None, help="Output directory (anchors.csv is written here)")
-    p.add_argument("--all-nfeatures", type=int, default=3000, help="Number of features for integration when generating anchors")
-    p.add_argument("--single-nfeatures", type=int, default=2000, help="Number of features per modality when generating anchors")
-    p.add_argument("--k-anchor", type=int, default=5, help="Number of neighbors when selecting anchors")
-    p.add_argument("--n-components", type=int, default=30, help="Dimensionality for CCA during anchor finding")
-    p.add_argument("--mode", choices=["v"], default=None, help="'v': positional anchors for paired data")
-    p.add_argument("--rna-latent-key", default="X_pca", help="Key for RNA latent representation in AnnData")
-    p.add_argument("--atac-latent-key", default="lsi49", help="Key for ATAC latent representation in AnnData")
-    p.add_argument("--rna-celltype-key", default="cell_type", help="Key for RNA cell type annotation in AnnData.obs")
-    p.add_argument("--atac-celltype-key", default="pred", help="Key for ATAC cell type annotation in AnnData.obs")
-    p.add_argument("--batch-size", type=int, default=256, help="Batch size for DataLoaders")
-    p.add_argument("--hidden-dims", type=parse_hidden_dims, default=[128, 64], help="Comma-separated hidden dimensions for VAE")
-    p.add_argument("--latent-dim", type=int, default=30, help="Latent dimension size for VAE")
-    p.add_argument("--no-balanced-sampler", dest="balanced_sampler", action="store_false", help="Disable balanced anchor sampling")
-    p.add_argument("--device", default="cuda:0", help="Torch device to use")
-    p.add_argument("--num-epochs", type=int, default=2000, help="Training epochs")
-    p.add_argument("--lambda-rna-kl", type=float, default=1.0, help="Weight for RNA KL divergence")
-    p.add_argument("--lambda-atac-kl", type=float, default=1.0, help="Weight for ATAC KL divergence")
-    p.add_argument("--alpha-rna-rec", type=float, default=20.0, help="Weight for RNA reconstruction loss")
-    p.add_argument("--alpha-atac-rec", type=float, default=20.0, help="Weight for ATAC reconstruction loss")
-    p.add_argument("--lambda-contra", type=float, default=300.0, help="Weight for anchor alignment loss")
-    p.add_argument("--temperature", type=float, default=0.5, help="Temperature for contrastive loss")
-    p.add_argument("--learning-rate", type=float, default=1e-3, help="Learning rate")
-    p.add_argument("--print-step", type=int, default=10, help="Logging interval in epochs")
-    p.set_defaults(func=run_train, balanced_sampler=True)
-    return parser
+    top = argparse.ArgumentParser(
+        prog="scmiac", description="scMIAC anchor search on MI355X: drop-in for the anchor stage of `scmiac train`")
+    commands = top.add_subparsers(dest="command", help="Available commands")
+    train = commands.add_parser(
+        "train", help="find cell-type-filtered MNN anchors and write anchors.csv (training follows if scMIAC is installed)")
+    for flag, default, kind, text in _TRAIN_OPTIONS:
+        extra = {} if kind is None else {"type": kind}
+        train.add_argument(flag, default=default, help=f"{text} (default: {default})", **extra)
+    train.add_argument("--mode", choices=["v"], default=None,
+                       help="v: the two files hold the same cells in the same order; pair them by position, no search")
+    train.add_argument("--no-balanced-sampler", dest="balanced_sampler", action="store_false", default=True,
+                       help="draw anchor batches uniformly instead of weighting by 1 / cell-type frequency")
+    train.set_defaults(func=run_train)
+    return top
 
 
 def main(argv: Sequence[str] | None = None) -> int:
+    """Entry point of the ``scmiac`` command: 1 (after printing the help) when no command was
+    given, otherwise the command's own status."""
+    words = list(sys.argv[1:] if argv is None else argv)
     parser = build_parser()
-    if argv is None:
-        argv = sys.argv[1:]
-    if not argv:
+    args = parser.parse_args(words) if words else None
+    handler = getattr(args, "func", None)
+    if handler is None:
         parser.print_help()
         return 1
-    args = parser.parse_args(argv)
-    if not hasattr(args, "func"):
-        parser.print_help()
-        return 1
-    return args.func(args)
+    return handler(args)
 
 
 if __name__ == "__main__":

@@ -126,6 +126,18 @@ int scmiac_knn_grid_plan(int64_t n, int64_t m, int d, int k, int splits, int64_t
     return SCMIAC_OK;
 }
 
+int scmiac_knn_kernel_name(int64_t n, int64_t m, int d, int k, int splits, char* buf, size_t buf_bytes) {
+    if (!buf || buf_bytes == 0) return fail(SCMIAC_ERR_ARG, "buf is NULL or empty");
+    int rc = check_knn_args(n, m, d, k);
+    if (rc) return rc;
+    KnnGeometry g = knn_geometry(n, m, d, k, splits);
+    if (g.D2 < 0) return fail(SCMIAC_ERR_ARG, "unsupported feature dimension %d", d);
+    const FusedTuning tn = knn_get_tuning();
+    snprintf(buf, buf_bytes, "fused_knn_kernel<%d, %d, %d, %d, %s, %s>", g.D2, g.nw, g.RT, g.pcap,
+             g.gp ? "true" : "false", (tn.diag || tn.ablate) ? "true" : "false");
+    return SCMIAC_OK;
+}
+
 int scmiac_knn_search(const float* q, int64_t n, const float* r, int64_t m, int d, int k,
                       int64_t col_offset, int merge, int splits, int32_t* idx, float* dist2, float* dist,
                       double* lower_bound, int32_t* uncertified_rows, int32_t* n_uncertified,

@@ -347,7 +347,7 @@ class SeuratIntegration:
             U = normalize(U, axis=1)
             V = normalize(V, axis=1)
         elif dim_red == "precomputed":
-            print("———————————————————————————————————" * 2)
+            print("———————————————————————————————————" * 2)  # anchors.py:974
             print("1. get U,V")
             U, V = self._prepare_matrix(i, j, key_anchor=key_anchor)
             print(f"U.shape:{U.shape}")
@@ -358,6 +358,9 @@ class SeuratIntegration:
         else:
             raise ValueError(f"Dimension reduction method {dim_red} is not supported.")
 
+        rule = "———————————————————————————————————" * 2
+        if dim_red == "precomputed":  # the reference rules this step off in that branch only (anchors.py:980)
+            print(rule)
         print("4. find MNN of U and V to find anchors")
         _k = max(_temp for _temp in [k_anchor, k_local, k_score] if _temp is not None)
         _k = min(min_sample - 2, _k)
@@ -366,8 +369,12 @@ class SeuratIntegration:
             i=i, j=j, U=U, V=V, k=_k, k_anchor=k_anchor, k_score=k_score)
 
         filtered = False
-        if k_filter is not None and high_dim_feature is not None:
+        if dim_red != "precomputed":  # announced whether or not the filter runs (anchors.py:894)
             print("5. filter anchors by high dimensional neighbors")
+        if k_filter is not None and high_dim_feature is not None:
+            if dim_red == "precomputed":  # ... and only with the filter here (anchors.py:989-992)
+                print(rule)
+                print("5. filter anchors by high dimensional neighbors")
             if self.n_cells[i] >= self.n_cells[j]:
                 raw_anchors = filter_anchor(anchor=raw_anchors, adata_ref=adata1, adata_qry=adata2,
                                             scale_ref=scale1, scale_qry=scale2,

@@ -1,0 +1,110 @@
+"""The benchmark configurations at their full size on one GPU.
+
+* the headline workload (1M x 1M, d=50, k=30, bench.py's seeds): a seeded row sample against
+  the CPU oracle, and on every row the properties that need no oracle (distances ascending,
+  ties in row-number order, no row listed twice, all row numbers valid);
+* one rank's share of the 4M x 2M, d=64 unit-norm ring workload: its 500k query rows against
+  the 2M reference rows arriving as 8 blocks of 250k, merged through ``col_offset`` /
+  ``merge`` with the direct-evaluation pass per block afterwards, exactly what ``knn_ring``
+  does on 8 ranks; per-block timings and uncertified-row counts are written to
+  ``gpurun_out/`` for the record.
+"""
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle
+from scmiac_amd import _hip
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+import bench  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _row_properties(st, m):
+    """Oracle-free checks over every row of a finished table."""
+    idx, d2 = st.idx, st.dist2
+    assert bool((idx >= 0).all()) and bool((idx < m).all())
+    assert bool((d2[:, 1:] >= d2[:, :-1]).all()), "distances not ascending"
+    tie = d2[:, 1:] == d2[:, :-1]
+    assert bool((idx[:, 1:][tie] > idx[:, :-1][tie]).all()), "ties not in row-number order"
+    srt = torch.sort(idx, dim=1).values
+    assert bool((srt[:, 1:] != srt[:, :-1]).all()), "a reference row is listed twice"
+    assert bool(torch.isfinite(st.dist).all())
+
+
+def _record(name, payload):
+    out = ROOT / "gpurun_out"
+    try:
+        out.mkdir(exist_ok=True)
+        (out / name).write_text(json.dumps(payload, indent=1) + "\n")
+    except OSError:
+        pass
+
+
+def test_headline_workload_full_size():
+    U, V, _, _, d = bench.make_latents("c3")
+    n, m, k = U.shape[0], V.shape[0], 30
+    assert (n, m, d) == (1_000_000, 1_000_000, 50)
+    q, r = torch.from_numpy(U).cuda(), torch.from_numpy(V).cuda()
+    st = _hip.knn_search(q, r, k)
+    torch.cuda.synchronize()
+    _row_properties(st, m)
+    rows = np.sort(np.random.default_rng(2024).choice(n, 2000, replace=False))
+    idx_o, d2_o = oracle.knn_dist2(U[rows], V, k)
+    rows_t = torch.from_numpy(rows).cuda()
+    np.testing.assert_array_equal(st.idx[rows_t].cpu().numpy(), idx_o)
+    np.testing.assert_array_equal(st.dist2[rows_t].cpu().numpy(), d2_o)
+    # the same table again: bit-identical (nothing depends on scheduling)
+    st2 = _hip.knn_search(q, r, k)
+    assert torch.equal(st.idx, st2.idx) and torch.equal(st.dist2, st2.dist2)
+    _record("full_size_c3.json", {"n": n, "m": m, "d": d, "k": k, "rows_vs_oracle": len(rows), "index_mismatches": 0,
+                                  "uncertified_rows": int(st.n_uncertified.item())})
+
+
+def test_ring_workload_one_rank_share_in_eight_blocks():
+    U, V, _, _, d = bench.make_latents("c5shard")
+    n, m, k, nblk = U.shape[0], V.shape[0], 30, 8
+    assert (n, m, d) == (500_000, 2_000_000, 64)
+    q, r = torch.from_numpy(U).cuda(), torch.from_numpy(V).cuda()
+    per = m // nblk
+    flops_blk = 2.0 * n * per * d
+    state, blocks = None, []
+    for b in range(nblk):
+        _hip.set_timing(True)
+        state = _hip.knn_search(q, r[b * per:(b + 1) * per], k, col_offset=b * per, state=state, exact_fallback=False)
+        ms, launches = _hip.fused_ms()
+        _hip.set_timing(False)
+        assert launches == 1
+        blocks.append({"block": b, "fused_ms": round(ms, 3), "frac_of_fp32_mfma_peak": round(flops_blk / (ms * 1e-3) / 157.3e12, 4),
+                       "n_uncertified": int(state.n_uncertified.item())})
+    # rows the last certificate could not prove: direct evaluation against every block (the ring's second trip)
+    n_unc = int(state.n_uncertified.item())
+    rows = state.uncertified_rows[:max(n_unc, 1)].clone()
+    n_rows = torch.tensor([n_unc], dtype=torch.int32, device="cuda")
+    for b in range(nblk):
+        _hip.knn_exact_rows(q, r[b * per:(b + 1) * per], k, rows, n_rows, state, col_offset=b * per)
+    torch.cuda.synchronize()
+    _row_properties(state, m)
+    # one stream over all 2M rows gives the same table
+    _hip.set_timing(True)
+    whole = _hip.knn_search(q, r, k)
+    ms_whole, _ = _hip.fused_ms()
+    _hip.set_timing(False)
+    assert torch.equal(whole.idx, state.idx) and torch.equal(whole.dist2, state.dist2)
+    sample = np.sort(np.random.default_rng(5005).choice(n, 500, replace=False))
+    idx_o, d2_o = oracle.knn_dist2(U[sample], V, k)
+    st = torch.from_numpy(sample).cuda()
+    np.testing.assert_array_equal(state.idx[st].cpu().numpy(), idx_o)
+    np.testing.assert_array_equal(state.dist2[st].cpu().numpy(), d2_o)
+    _record("full_size_c5_blocks.json", {
+        "n": n, "m": m, "d": d, "k": k, "blocks": blocks, "rows_vs_oracle": len(sample), "index_mismatches": 0,
+        "uncertified_after_last_block": n_unc,
+        "single_stream": {"fused_ms": round(ms_whole, 3),
+                          "frac_of_fp32_mfma_peak": round(2.0 * n * m * d / (ms_whole * 1e-3) / 157.3e12, 4)}})

@@ -50,7 +50,11 @@ def main():
                 "HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB",
     }
     json.dump(out, open(out_dir / f"{a.tag}_pmc_summary.json", "w"), indent=1)
-    json.dump({"workload": a.workload, "n_local": a.n_local, "kernel": fk, "FETCH_SIZE_KB": v["FETCH_SIZE"],
+    import sys
+    sys.path.insert(0, str(ROOT))
+    import bench
+    json.dump({"workload": a.workload, "n_local": a.n_local, "kernel": fk, "source_sha256": bench.kernel_source_hash(),
+               "FETCH_SIZE_KB": v["FETCH_SIZE"],
                "WRITE_SIZE_KB": v["WRITE_SIZE"], "hbm_bytes_per_launch": hbm,
                "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE doubled as the gfx950 "
                        "correction for wide coalesced reads prescribes; one launch = one table of this workload"},
