@@ -23,9 +23,19 @@ def main():
     ap.add_argument("--bench", required=True)
     ap.add_argument("--tag", default="r01_c3")
     ap.add_argument("--workload", default="c3")
-    ap.add_argument("--n-local", type=int, default=1_000_000)
-    a = ap.parse_args()
-    out_dir = ROOT / "profiles"
+    ap.add_argument("--n-local", type=int, default=None, help="query rows per launch (default: the workload's, or --n)")
+    ap.add_argument("--out-dir", default=str(ROOT / "profiles"))
+    ap.add_argument("--n", type=int, default=None)
+    ap.add_argument("--m", type=int, default=None)
+    a, _ = ap.parse_known_args()  # further bench.py options are passed through by the caller and ignored here
+    out_dir = Path(a.out_dir)
+    out_dir.mkdir(parents=True, exist_ok=True)
+    import sys
+    sys.path.insert(0, str(ROOT))
+    import bench
+    if a.n_local is None:
+        a.n_local = a.n or bench.WORKLOADS[a.workload][0]
+    overridden = bool(a.n or a.m)
     def newest(pattern):  # a directory may hold the outputs of earlier runs as well
         return max(glob.glob(pattern), key=os.path.getmtime)
 
@@ -50,15 +60,15 @@ def main():
                 "HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB",
     }
     json.dump(out, open(out_dir / f"{a.tag}_pmc_summary.json", "w"), indent=1)
-    import sys
-    sys.path.insert(0, str(ROOT))
-    import bench
+    # the file bench.py reads `roofline.traffic` from describes the default workload only
+    traffic_file = out_dir / ("fused_knn_hbm_traffic.json" if a.workload == "c3" and not overridden
+                              else f"{a.tag}_hbm_traffic.json")
     json.dump({"workload": a.workload, "n_local": a.n_local, "kernel": fk, "source_sha256": bench.kernel_source_hash(),
                "FETCH_SIZE_KB": v["FETCH_SIZE"],
                "WRITE_SIZE_KB": v["WRITE_SIZE"], "hbm_bytes_per_launch": hbm,
                "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE doubled as the gfx950 "
                        "correction for wide coalesced reads prescribes; one launch = one table of this workload"},
-              open(out_dir / "fused_knn_hbm_traffic.json", "w"), indent=1)
+              open(traffic_file, "w"), indent=1)
     line = [l for l in open(a.bench).read().splitlines() if l.startswith("{")][-1]
     (out_dir / f"{a.tag}_bench.json").write_text(line + "\n")
     print(json.dumps(out["_derived"], indent=1))
