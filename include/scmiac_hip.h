@@ -115,6 +115,23 @@ SCMIAC_API int scmiac_find_mnn(const int32_t *g12, int64_t n1, int64_t ld12, con
                     int64_t ld21, int ka, int64_t *pairs, int64_t *n_pairs, int32_t *status,
                     void *workspace, size_t workspace_bytes, void *stream);
 
+/*
+ * scmiac_find_mnn for callers that cannot allocate device memory or carry a workspace (code
+ * under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  It has no
+ * counterpart in the reference.  Same arguments and result as scmiac_find_mnn minus the
+ * workspace: the compaction scratch is a static device array inside the library
+ * (about 16.1 MiB on every GPU the library is used on, held until the process ends), which
+ * bounds the problem: n1 * ka <= SCMIAC_MNN_NOALLOC_MAX_ITEMS, else SCMIAC_ERR_ARG.
+ * Calls no hipMalloc / hipFree and no allocating routine; work is enqueued on `stream`.
+ * The first call on each device looks the array's address up (make that call outside graph
+ * capture).  All calls on one GPU share the array: calls that overlap in time on the same
+ * GPU (different streams or threads) race; serialise them.
+ */
+#define SCMIAC_MNN_NOALLOC_MAX_ITEMS (8 * 1024 * 1024)
+SCMIAC_API int scmiac_find_mnn_noalloc(const int32_t *g12, int64_t n1, int64_t ld12, const int32_t *g21,
+                                       int64_t n2, int64_t ld21, int ka, int64_t *pairs, int64_t *n_pairs,
+                                       int32_t *status, void *stream);
+
 /* Scratch bytes for the ordered-compaction passes over `n_items` flags. */
 SCMIAC_API int scmiac_compact_workspace_size(int64_t n_items, size_t *bytes);
 

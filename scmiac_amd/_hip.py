@@ -32,6 +32,7 @@ _SIGNATURES = {
     "scmiac_knn_exact_rows": ([_vp, _i64, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
                               _c.c_int),
     "scmiac_find_mnn": ([_vp, _i64, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _sz, _vp], _c.c_int),
+    "scmiac_find_mnn_noalloc": ([_vp, _i64, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp], _c.c_int),
     "scmiac_compact_workspace_size": ([_i64, _c.POINTER(_sz)], _c.c_int),
     "scmiac_snn_score": ([_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp],
                          _c.c_int),

@@ -227,6 +227,59 @@ int scmiac_find_mnn(const int32_t* g12, int64_t n1, int64_t ld12, const int32_t*
     return SCMIAC_OK;
 }
 
+// ---- allocation-free variant of scmiac_find_mnn ------------------------------------------
+// Its compaction scratch (flags + per-block counts) is this file-scope device array instead of
+// a caller workspace.  Every GPU the library runs on holds its own copy at its own address;
+// `scratch` below is only the host-side handle of the symbol, never a device address: host
+// code uses the per-device pointer from hipGetSymbolAddress wherever the memory is meant.
+static constexpr size_t kMnnStaticBytes =
+    2 * (size_t)SCMIAC_MNN_NOALLOC_MAX_ITEMS + 2 * (((size_t)SCMIAC_MNN_NOALLOC_MAX_ITEMS / 1024 + 2) * 8 + 256) + 512;
+static __device__ __align__(256) unsigned char scratch[kMnnStaticBytes];
+static constexpr int kMaxDevices = 64;
+static std::mutex g_scratch_mu;
+static void* g_scratch_ptr[kMaxDevices] = {};  // device address of `scratch` on each GPU, once resolved
+
+// Address of this device's copy of `scratch` (resolved on the first call per device).
+static int scratch_for_current_device(void** out) {
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev), "hipGetDevice");
+    if (dev < 0 || dev >= kMaxDevices) return fail(SCMIAC_ERR_ARG, "device ordinal %d outside 0..%d", dev, kMaxDevices - 1);
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void* ptr = nullptr;
+        hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return hip_fail(e, "hipGetSymbolAddress(scratch)");
+        if (!ptr) return fail(SCMIAC_ERR_HIP, "hipGetSymbolAddress(scratch) returned a null address");
+        g_scratch_ptr[dev] = ptr;
+    }
+    *out = g_scratch_ptr[dev];
+    return SCMIAC_OK;
+}
+
+int scmiac_find_mnn_noalloc(const int32_t* g12, int64_t n1, int64_t ld12, const int32_t* g21, int64_t n2,
+                            int64_t ld21, int ka, int64_t* pairs, int64_t* n_pairs, int32_t* status, void* stream_) {
+    if (n1 < 0 || n2 < 0 || ka < 0) return fail(SCMIAC_ERR_ARG, "negative size");
+    if (ka > ld12 || ka > ld21)
+        return fail(SCMIAC_ERR_ARG, "k_anchor=%d exceeds the neighbour columns (%lld, %lld)", ka,
+                    (long long)ld12, (long long)ld21);
+    const int64_t items = n1 * (int64_t)ka;
+    if (items > (int64_t)SCMIAC_MNN_NOALLOC_MAX_ITEMS)
+        return fail(SCMIAC_ERR_ARG, "n1 * k_anchor = %lld exceeds the static scratch (%lld candidate pairs); "
+                    "use scmiac_find_mnn with a workspace", (long long)items, (long long)SCMIAC_MNN_NOALLOC_MAX_ITEMS);
+    if (!n_pairs || !status) return fail(SCMIAC_ERR_ARG, "NULL device pointer");
+    if (items > 0 && (!g12 || !g21 || !pairs)) return fail(SCMIAC_ERR_ARG, "NULL device pointer");
+    if (compact_workspace_bytes(items) > kMnnStaticBytes)
+        return fail(SCMIAC_ERR_WORKSPACE, "internal: static scratch smaller than the compaction needs");
+    void* ws = nullptr;
+    if (int rc = scratch_for_current_device(&ws)) return rc;
+    // every byte of the scratch the kernels read they have written in this call (flags of all
+    // candidate pairs, counts of all blocks): nothing left over from the previous call matters
+    HIP_TRY(launch_find_mnn(g12, n1, ld12, g21, n2, ld21, ka, reinterpret_cast<long long*>(pairs),
+                            reinterpret_cast<long long*>(n_pairs), status, ws, static_cast<hipStream_t>(stream_)),
+            "find_mnn");
+    return SCMIAC_OK;
+}
+
 int scmiac_snn_score(const int64_t* pairs, const int64_t* n_pairs, int64_t n_pairs_max, const int32_t* g11,
                      const int32_t* g12, const int32_t* g21, const int32_t* g22, int64_t n1, int64_t n2,
                      int64_t ld, int ks, int32_t* score, int64_t* hist, void* stream_) {
