@@ -186,10 +186,12 @@ SCMIAC_API int scmiac_anchor_filter(const int64_t *pairs, const int64_t *n_pairs
  *                  = the library's choice.  A combination that is not compiled for any
  *                  feature size is rejected with SCMIAC_ERR_ARG; one that is compiled for
  *                  other feature sizes only is ignored for the rest.
+ *   no_locality    1: stream the reference rows in the caller's order instead of regrouping
+ *                  both sets by nearest pivot first (same result, A/B timing aid)
  * Thread-safe; affects searches planned after the call.
  */
 SCMIAC_API int scmiac_knn_set_tuning(int slots, int tail_min_rows, int no_tail, int ablate, int diag, int nw,
-                                     int rt, int pcap, int gp);
+                                     int rt, int pcap, int gp, int no_locality);
 
 /*
  * Diagnostic aid (no counterpart in the reference).  When the `diag` knob of

@@ -39,15 +39,22 @@ struct KnnWs {
     unsigned long long* lists;
     void* pend;  // pending-candidate buffers, when the fused kernel keeps them in global memory
     unsigned* maxnorm;
+    float* tau_out;  // [list_rows] threshold every shortlist ended with
+    float* tau0;     // [n_pad] thresholds to start from (merge mode)
+    LocalityWs loc;  // pivot partition (all NULL when the geometry has no cells)
     unsigned long long* diag;  // per-wave counters of the fused kernel (diagnostic runs)
     size_t diag_offset, diag_bytes;
     size_t total;
 };
-static KnnWs knn_carve(void* ws, long long n, const KnnGeometry& g) {
-    (void)n;
+static KnnWs knn_carve(void* ws, long long n, long long m, int d, const KnnGeometry& g) {
     unsigned char* p = static_cast<unsigned char*>(ws);
     KnnWs w;
     size_t off = 0;
+    auto take = [&](size_t bytes) {
+        unsigned char* at = p + off;
+        off += up256(bytes);
+        return at;
+    };
     w.qp = reinterpret_cast<float*>(p + off);
     off += up256(sizeof(float) * (size_t)g.n_pad * g.rowf);
     w.rp = reinterpret_cast<float*>(p + off);
@@ -60,6 +67,23 @@ static KnnWs knn_carve(void* ws, long long n, const KnnGeometry& g) {
     if (g.gp) off += up256(8 * (size_t)g.list_rows * g.pcap);
     w.maxnorm = reinterpret_cast<unsigned*>(p + off);
     off += 256;
+    w.tau_out = reinterpret_cast<float*>(take(sizeof(float) * (size_t)g.list_rows));
+    w.tau0 = reinterpret_cast<float*>(take(sizeof(float) * (size_t)g.n_pad));
+    w.loc = LocalityWs{};
+    if (g.cells > 0) {
+        const size_t nbq = (size_t)((n + 255) / 256), nbr = (size_t)((m + 255) / 256);
+        w.loc.pivT = reinterpret_cast<float*>(take(sizeof(float) * (size_t)d * g.cells_pad));
+        w.loc.pnorm = reinterpret_cast<float*>(take(sizeof(float) * (size_t)g.cells_pad));
+        w.loc.cell_q = take((size_t)n);
+        w.loc.cell_r = take((size_t)m);
+        w.loc.hist_q = reinterpret_cast<int*>(take(sizeof(int) * nbq * g.cells));
+        w.loc.hist_r = reinterpret_cast<int*>(take(sizeof(int) * nbr * g.cells));
+        w.loc.cstart_q = reinterpret_cast<int*>(take(sizeof(int) * (size_t)(g.cells + 1)));
+        w.loc.cstart_r = reinterpret_cast<int*>(take(sizeof(int) * (size_t)(g.cells + 1)));
+        w.loc.perm_q = reinterpret_cast<int*>(take(sizeof(int) * (size_t)n));
+        w.loc.perm_r = reinterpret_cast<int*>(take(sizeof(int) * (size_t)m));
+        w.loc.home = reinterpret_cast<int*>(take(sizeof(int) * 2 * (size_t)g.nqb));
+    }
     w.diag = reinterpret_cast<unsigned long long*>(p + off);
     w.diag_offset = off;
     w.diag_bytes = sizeof(unsigned long long) * 12 * (size_t)g.blocks * g.nw;
@@ -97,7 +121,7 @@ int scmiac_knn_workspace_size(int64_t n, int64_t m, int d, int k, int splits, si
     if (rc) return rc;
     KnnGeometry g = knn_geometry(n, m, d, k, splits);
     if (g.D2 < 0) return fail(SCMIAC_ERR_ARG, "unsupported feature dimension %d", d);
-    *bytes = knn_carve(nullptr, n, g).total;
+    *bytes = knn_carve(nullptr, n, m, d, g).total;
     return SCMIAC_OK;
 }
 
@@ -108,7 +132,7 @@ int scmiac_knn_diag_region(int64_t n, int64_t m, int d, int k, int splits, size_
     if (rc) return rc;
     KnnGeometry g = knn_geometry(n, m, d, k, splits);
     if (g.D2 < 0) return fail(SCMIAC_ERR_ARG, "unsupported feature dimension %d", d);
-    KnnWs w = knn_carve(nullptr, n, g);
+    KnnWs w = knn_carve(nullptr, n, m, d, g);
     *offset = w.diag_offset;
     *bytes = w.diag_bytes;
     *waves = g.blocks * g.nw;
@@ -152,14 +176,21 @@ int scmiac_knn_search(const float* q, int64_t n, const float* r, int64_t m, int 
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     KnnGeometry g = knn_geometry(n, m, d, k, splits);
     if (g.D2 < 0) return fail(SCMIAC_ERR_ARG, "unsupported feature dimension %d", d);
-    KnnWs w = knn_carve(workspace, n, g);
+    KnnWs w = knn_carve(workspace, n, m, d, g);
     if (w.total > workspace_bytes)
         return fail(SCMIAC_ERR_WORKSPACE, "workspace holds %zu bytes, %zu needed", workspace_bytes, w.total);
 
     HIP_TRY(hipMemsetAsync(w.maxnorm, 0, 256, stream), "memset maxnorm");
     HIP_TRY(hipMemsetAsync(n_uncertified, 0, sizeof(int32_t), stream), "memset n_uncertified");
-    HIP_TRY(launch_pack(q, n, d, g, -2.0f, w.qp, g.rowf, nullptr, g.n_pad, w.maxnorm, stream), "pack queries");
-    HIP_TRY(launch_pack(r, m, d, g, 1.0f, w.rp, g.ls, w.rnorm, g.m_pad, w.maxnorm, stream), "pack references");
+    if (g.cells > 0) HIP_TRY(launch_locality(q, n, r, m, d, g, w.loc, stream), "locality partition");
+    HIP_TRY(launch_pack(q, n, d, g, -2.0f, w.qp, g.rowf, nullptr, g.n_pad, w.maxnorm, w.loc.perm_q, stream), "pack queries");
+    HIP_TRY(launch_pack(r, m, d, g, 1.0f, w.rp, g.ls, w.rnorm, g.m_pad, w.maxnorm, w.loc.perm_r, stream), "pack references");
+    // merge mode: the running k-th distances bound what this block can contribute
+    const float* tau0 = nullptr;
+    if (merge && m > 0) {
+        HIP_TRY(launch_seed_tau(q, w.loc.perm_q, d, n, g, idx, dist2, k, w.maxnorm, w.tau0, stream), "seed thresholds");
+        tau0 = w.tau0;
+    }
     int slot = -1;  // event pair of this search, when timing is on
     {
         std::lock_guard<std::mutex> lock(g_timing_mu);
@@ -174,11 +205,13 @@ int scmiac_knn_search(const float* q, int64_t n, const float* r, int64_t m, int 
     }
     if (slot >= 0) HIP_TRY(hipEventRecord(g_ev0[slot], stream), "event record");
     const bool diag = knn_get_tuning().diag != 0;  // diagnostic runs: per-wave cycle counters
-    HIP_TRY(launch_fused(g, w.qp, w.rp, w.rnorm, w.lists, w.pend, n, knn_threshold_rank(k), diag ? w.diag : nullptr, stream),
+    HIP_TRY(launch_fused(g, w.qp, w.rp, w.rnorm, w.lists, w.pend, n, knn_threshold_rank(k), w.loc.home, tau0, w.tau_out,
+                         diag ? w.diag : nullptr, stream),
             "fused distance + top-k");
     if (slot >= 0) HIP_TRY(hipEventRecord(g_ev1[slot], stream), "event record");
-    HIP_TRY(launch_refine(q, w.qp, w.rp, d, n, g, w.lists, k, knn_threshold_rank(k), col_offset, merge, w.maxnorm, idx, dist2, dist,
-                          lower_bound, uncertified_rows, n_uncertified, stream),
+    HIP_TRY(launch_refine(q, w.qp, w.rp, d, n, g, w.lists, k, knn_threshold_rank(k), col_offset, merge, w.maxnorm, w.tau_out,
+                          w.loc.perm_q, w.loc.perm_r, idx, dist2, dist, lower_bound, uncertified_rows, n_uncertified,
+                          stream),
             "refine");
     if (exact_fallback)  // the shortlists are dead once refine has run: their memory is the scratch
         HIP_TRY(launch_exact_rows(q, r, d, n, m, k, col_offset, uncertified_rows, n_uncertified, idx, dist2,
@@ -329,9 +362,10 @@ int scmiac_knn_set_timing(int enabled) {
 }
 
 int scmiac_knn_set_tuning(int slots, int tail_min_rows, int no_tail, int ablate, int diag, int nw, int rt, int pcap,
-                          int gp) {
+                          int gp, int no_locality) {
     FusedTuning t{};
     t.slots = slots; t.tail_min_rows = tail_min_rows; t.no_tail = no_tail; t.ablate = ablate; t.diag = diag;
+    t.no_locality = no_locality;
     t.has_variant = (nw > 0 || rt > 0) ? 1 : 0;
     t.nw = nw; t.rt = rt; t.pcap = pcap; t.gp = gp;
     if (!knn_set_tuning(t))
@@ -357,8 +391,8 @@ int scmiac_knn_fused_ms(float* total_ms, int* launches) {
 
 // workspace of a count: the k-NN carve-up, with the thresholds and counts in the (unused)
 // shortlist region and the parked references in the pending-candidate region
-static size_t count_pend_offset_total(const KnnGeometry& g, int64_t n, KnnWs* w_out) {
-    KnnWs w = knn_carve(nullptr, n, g);
+static size_t count_pend_offset_total(const KnnGeometry& g, int64_t n, int64_t m, int d, KnnWs* w_out) {
+    KnnWs w = knn_carve(nullptr, n, m, d, g);
     if (w_out) *w_out = w;
     return up256(w.total) + up256(closer_count_pend_bytes(g));
 }
@@ -369,7 +403,7 @@ int scmiac_closer_count_workspace_size(int64_t n, int64_t m, int d, size_t* byte
     if (rc) return rc;
     KnnGeometry g = knn_geometry(n, m, d, 30, 0);
     if (g.D2 < 0) return fail(SCMIAC_ERR_ARG, "unsupported feature dimension %d", d);
-    *bytes = count_pend_offset_total(g, n, nullptr);
+    *bytes = count_pend_offset_total(g, n, m, d, nullptr);
     return SCMIAC_OK;
 }
 
@@ -385,10 +419,10 @@ int scmiac_closer_count(const float* q, int64_t n, const float* r, int64_t m, in
     KnnGeometry g = knn_geometry(n, m, d, 30, 0);
     if (g.D2 < 0) return fail(SCMIAC_ERR_ARG, "unsupported feature dimension %d", d);
     KnnWs w0;
-    size_t total = count_pend_offset_total(g, n, &w0);
+    size_t total = count_pend_offset_total(g, n, m, d, &w0);
     if (total > workspace_bytes)
         return fail(SCMIAC_ERR_WORKSPACE, "workspace holds %zu bytes, %zu needed", workspace_bytes, total);
-    KnnWs w = knn_carve(workspace, n, g);
+    KnnWs w = knn_carve(workspace, n, m, d, g);
     unsigned* pend = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + up256(w.total));
     float* lo = reinterpret_cast<float*>(w.lists);
     float* hi = lo + g.n_pad;
@@ -398,8 +432,8 @@ int scmiac_closer_count(const float* q, int64_t n, const float* r, int64_t m, in
         return fail(SCMIAC_ERR_WORKSPACE, "internal: threshold region too small");
     HIP_TRY(hipMemsetAsync(w.maxnorm, 0, 256, stream), "memset maxnorm");
     HIP_TRY(hipMemsetAsync(status, 0, sizeof(int32_t), stream), "memset status");
-    HIP_TRY(launch_pack(q, n, d, g, -2.0f, w.qp, g.rowf, nullptr, g.n_pad, w.maxnorm, stream), "pack queries");
-    HIP_TRY(launch_pack(r, m, d, g, 1.0f, w.rp, g.ls, w.rnorm, g.m_pad, w.maxnorm, stream), "pack references");
+    HIP_TRY(launch_pack(q, n, d, g, -2.0f, w.qp, g.rowf, nullptr, g.n_pad, w.maxnorm, nullptr, stream), "pack queries");
+    HIP_TRY(launch_pack(r, m, d, g, 1.0f, w.rp, g.ls, w.rnorm, g.m_pad, w.maxnorm, nullptr, stream), "pack references");
     HIP_TRY(launch_closer_count(g, q, r, match, d, n, m, w.qp, w.rp, w.rnorm, w.maxnorm, lo, hi, dmatch, cnt, pend,
                                 status, stream),
             "closer count");

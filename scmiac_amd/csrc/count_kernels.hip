@@ -197,18 +197,19 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
 #pragma unroll
     for (int r = 0; r < 16; ++r) accs[1][r] = big;  // "previous subtile" of the first one: nothing below hi
 
-    if (T > 0) SCMIAC_STAGE(0, 0);
+    if (T > 0) SCMIAC_STAGE(r_begin, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     bool dense = false;  // wave-uniform: skip the per-subtile question in this stage
     int hits = 0;        // subtiles of the current stage that had scores below `hi`
     for (int t = 0; t < T; ++t) {
-        if (t + 1 < T) SCMIAC_STAGE(t + 1, (t + 1) & 1);
+        if (t + 1 < T) SCMIAC_STAGE(r_begin + (long long)(t + 1) * RT, (t + 1) & 1);
         // asked again every eighth stage, so a stream that turns sparse is noticed
         dense = (t & 7) != 0 && (dense || hits >= NSUB - 1);
         hits = 0;
         const float* tb = tile + (t & 1) * RT * LS;
         const float* nb = tnorm + (t & 1) * RT;
+        const long long cur_row0 = r_begin + (long long)t * RT;  // first reference row of this stage
         SCMIAC_LOAD_NORMS(0, 0);
         SCMIAC_LOAD_GROUP(0, 0, 0);
         SCMIAC_LOAD_GROUP(0, 1, 1);

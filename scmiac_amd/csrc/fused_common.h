@@ -166,15 +166,16 @@ __device__ __forceinline__ float exact_dist2_packed(const float4* __restrict__ q
 }
 
 // ---- the stage loop, as macros expanded inside a kernel -------------------------------
-// They use the kernel's locals by name: tile_lds, tnorm_lds, Rp, rnorm, r_begin, wave, lane,
-// j, hh, tb, nb, t, fr[3][4], accs[2], qf[], ref0s[2] and the constants RT, LS, D2P, NW,
+// They use the kernel's locals by name: tile_lds, tnorm_lds, Rp, rnorm, wave, lane,
+// j, hh, tb, nb, cur_row0 (first reference row of the stage being scored, wave-uniform),
+// fr[3][4], accs[2], qf[], ref0s[2] and the constants RT, LS, D2P, NW,
 // NCHUNK, LD_ITERS, NORM_CHUNKS, STAGE_BYTES, NGRP, NSUB, D2.  SCMIAC_TEST_PREV(PRV_) is
 // supplied by the kernel: what to do with the finished scores in accs[PRV_].
-// Stage copy global -> LDS without registers: RT packed rows are one contiguous byte
-// range in both, and so are their norms.
-#define SCMIAC_STAGE(T_, BUF_)                                                                      \
+// Stage copy global -> LDS without registers: the RT packed rows from ROW0_ on are one
+// contiguous byte range in both, and so are their norms.
+#define SCMIAC_STAGE(ROW0_, BUF_)                                                                   \
     do {                                                                                            \
-        const long long row0_ = r_begin + (long long)(T_) * RT;                                     \
+        const long long row0_ = (ROW0_);                                                            \
         const char* src_ = reinterpret_cast<const char*>(Rp + row0_ * LS);                          \
         const unsigned dst_ = tile_lds + (unsigned)((BUF_) * STAGE_BYTES);                          \
         _Pragma("unroll") for (int i = 0; i < LD_ITERS; ++i) {                                      \
@@ -231,7 +232,7 @@ __device__ __forceinline__ float exact_dist2_packed(const float4* __restrict__ q
             }                                                                                       \
         }                                                                                           \
         _Pragma("unroll") for (int g = 1; g < NGRP; ++g) SCMIAC_GROUP(CUR_, SUB_, g);               \
-        ref0s[CUR_] = (unsigned)(r_begin + (long long)t * RT + (SUB_) * 32); /* wave-uniform */     \
+        ref0s[CUR_] = (unsigned)(cur_row0 + (SUB_) * 32); /* wave-uniform */                        \
     } while (0)
 
 }  // namespace scmiac

@@ -42,6 +42,24 @@ struct KnnGeometry {
     FusedTail tail;
     long long list_rows;   // 64-entry shortlists in the workspace
     int blocks;            // grid size of the fused kernel
+    int cells;             // pivots of the locality partition (0: rows keep the caller's order)
+    int cells_pad;         // cells rounded up to a multiple of 8
+    int home_max;          // most home stages a query block streams ahead of its chunk
+};
+
+// device scratch of the locality partition (carved out of the search workspace)
+struct LocalityWs {
+    float* pivT;            // [d][cells_pad]
+    float* pnorm;           // [cells_pad]
+    unsigned char* cell_q;  // [n]
+    unsigned char* cell_r;  // [m]
+    int* hist_q;            // [ceil(n / 256)][cells]
+    int* hist_r;            // [ceil(m / 256)][cells]
+    int* cstart_q;          // [cells + 1]
+    int* cstart_r;          // [cells + 1]
+    int* perm_q;            // [n]: packed query position -> caller's row
+    int* perm_r;            // [m]: packed reference row -> caller's row
+    int* home;              // [nqb][2]
 };
 
 // Diagnostic / tuning knobs of the fused kernel's grid plan (all zero = product behaviour).
@@ -51,6 +69,7 @@ struct FusedTuning {
     int no_tail;        // 1: never split the last round's query blocks further
     int ablate;         // ablation bits of the diagnostic kernel instantiation
     int diag;           // 1: per-wave cycle counters into the workspace
+    int no_locality;    // 1: stream the references in the caller's order (no pivot partition)
     int has_variant;    // 1: use (nw, rt, pcap, gp) where that combination is compiled
     int nw, rt, pcap, gp;
 };
@@ -64,14 +83,20 @@ inline int knn_threshold_rank(int k) { return (k + 6 < 64) ? k + 6 : 64; }
 KnnGeometry knn_geometry(long long n, long long m, int d, int k, int splits);
 
 hipError_t launch_pack(const float* X, long long n, int d, const KnnGeometry& g, float scale, float* Xp,
-                       int ld, float* norms, long long n_pad, unsigned* maxnorm_bits, hipStream_t stream);
+                       int ld, float* norms, long long n_pad, unsigned* maxnorm_bits, const int* perm,
+                       hipStream_t stream);
+hipError_t launch_locality(const float* Q, long long n, const float* R, long long m, int d, const KnnGeometry& g,
+                           const LocalityWs& w, hipStream_t stream);
+hipError_t launch_seed_tau(const float* Q, const int* perm_q, int d, long long n, const KnnGeometry& g, const int* idx,
+                           const float* d2, int k, const unsigned* maxnorm_bits, float* tau0, hipStream_t stream);
 hipError_t launch_fused(const KnnGeometry& g, const float* Qp, const float* Rp, const float* rnorm,
-                        unsigned long long* lists, void* pend_g, long long n, int kt,
-                        unsigned long long* diag, hipStream_t stream);
+                        unsigned long long* lists, void* pend_g, long long n, int kt, const int* home,
+                        const float* tau0, float* tau_out, unsigned long long* diag, hipStream_t stream);
 hipError_t launch_refine(const float* Q, const float* Qp, const float* Rp, int d, long long n, const KnnGeometry& g,
                          const unsigned long long* lists, int k, int kt, long long col_offset, int merge,
-                         const unsigned* maxnorm_bits, int* idx, float* d2, float* dist, double* lb,
-                         int* fail_rows, int* n_fail, hipStream_t stream);
+                         const unsigned* maxnorm_bits, const float* tau_lists, const int* perm_q, const int* perm_r,
+                         int* idx, float* d2, float* dist, double* lb, int* fail_rows, int* n_fail,
+                         hipStream_t stream);
 hipError_t launch_exact_rows(const float* Q, const float* R, int d, long long n, long long m, int k,
                              long long col_offset, const int* rows, const int* n_rows, int* idx,
                              float* d2, float* dist, void* scratch, size_t scratch_bytes,

@@ -44,15 +44,23 @@ static constexpr int PACK_ROWS = 64;
 __global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict__ X, long long n, int d, int D2,
                                                         int D2P, float scale, float* __restrict__ Xp, int ld,
                                                         float* __restrict__ norms, long long n_pad,
-                                                        unsigned* __restrict__ maxnorm_bits) {
+                                                        unsigned* __restrict__ maxnorm_bits,
+                                                        const int* __restrict__ perm /* packed row -> row of X, or NULL */) {
     __shared__ float rows[PACK_ROWS * SCMIAC_KNN_MAX_D_INTERNAL];
     const long long row0 = (long long)blockIdx.x * PACK_ROWS;
     if (row0 >= n_pad) return;
     const int nrows = (int)((n_pad - row0) < PACK_ROWS ? (n_pad - row0) : PACK_ROWS);
     const long long real = n - row0;  // rows of this block that exist in X (may be <= 0)
     const int nreal = real < 0 ? 0 : (real < nrows ? (int)real : nrows);
-    const float* src = X + row0 * d;
-    for (int i = threadIdx.x; i < nreal * d; i += blockDim.x) rows[i] = src[i];
+    if (perm) {  // gather: whole rows (d contiguous floats each) from where the permutation says
+        for (int i = threadIdx.x; i < nreal * d; i += blockDim.x) {
+            const int r = i / d;
+            rows[i] = X[(long long)perm[row0 + r] * d + (i - r * d)];
+        }
+    } else {
+        const float* src = X + row0 * d;
+        for (int i = threadIdx.x; i < nreal * d; i += blockDim.x) rows[i] = src[i];
+    }
     __syncthreads();
     float* dst = Xp + row0 * ld;
     for (int i = threadIdx.x; i < nrows * ld; i += blockDim.x) {
@@ -76,6 +84,177 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict_
             atomicMax(maxnorm_bits, __float_as_uint(acc));  // acc >= 0: bit order == value order
         }
     }
+}
+
+// --------------------------------------------------------------------------------
+// Locality partition.  The candidate path of the fused kernel is cheap once a query's
+// threshold is tight, and it becomes tight as soon as the query has seen its near
+// neighbours.  So both sets are regrouped by nearest pivot (C reference rows taken at even
+// spacing): queries of a block then share a cell, and the block streams the reference rows
+// of that cell -- its "home" stages -- before the rest.  Any assignment gives a correct
+// search (the result is put back in the caller's row order and row numbers); a good one
+// makes it fast.  Kernels: pivots -> cell of every row + per-block cell counts -> offsets
+// -> stable scatter into a permutation -> home stages per query block.
+// --------------------------------------------------------------------------------
+static constexpr int CELL_ROWS = 256;     // rows per block of the partition kernels
+static constexpr int CELL_TP = 8;         // pivots scored together per thread
+
+// pivT[i][c] = feature i of pivot c (= row (c * m) / C of R), pnorm[c] = |pivot c|^2
+__global__ void pivots_kernel(const float* __restrict__ R, long long m, int d, int C, int Cpad,
+                              float* __restrict__ pivT, float* __restrict__ pnorm) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Cpad) return;
+    float acc = 0.0f;
+    const float* row = R + ((long long)c * m / C) * d;
+    for (int i = 0; i < d; ++i) {
+        const float v = c < C ? row[i] : 0.0f;
+        pivT[i * Cpad + c] = v;
+        acc = __fmaf_rn(v, v, acc);
+    }
+    pnorm[c] = c < C ? acc : __builtin_inff();
+}
+
+// cell[row] = pivot with the smallest |p|^2 - 2 x.p (lowest pivot number among equals);
+// blockhist[block][c] = rows of this block in cell c.
+__global__ __launch_bounds__(CELL_ROWS) void assign_cells_kernel(const float* __restrict__ X, long long n, int d,
+                                                                 const float* __restrict__ pivT,
+                                                                 const float* __restrict__ pnorm, int C, int Cpad,
+                                                                 unsigned char* __restrict__ cell,
+                                                                 int* __restrict__ blockhist) {
+    extern __shared__ __attribute__((aligned(16))) float csm[];
+    float* pT = csm;                       // [d][Cpad]
+    float* pn = pT + d * Cpad;             // [Cpad]
+    float* xT = pn + Cpad;                 // [d][CELL_ROWS + 1]: feature-major, conflict-free both ways
+    int* hist = reinterpret_cast<int*>(xT + d * (CELL_ROWS + 1));  // [Cpad]
+    const int tid = threadIdx.x;
+    const long long row0 = (long long)blockIdx.x * CELL_ROWS;
+    const int nrows = (int)((n - row0) < CELL_ROWS ? (n - row0) : CELL_ROWS);
+    for (int i = tid; i < d * Cpad; i += CELL_ROWS) pT[i] = pivT[i];
+    for (int i = tid; i < Cpad; i += CELL_ROWS) { pn[i] = pnorm[i]; hist[i] = 0; }
+    const float* src = X + row0 * d;
+    for (int e = tid; e < nrows * d; e += CELL_ROWS) {
+        const int r = e / d, i = e - r * d;
+        xT[i * (CELL_ROWS + 1) + r] = src[e];
+    }
+    __syncthreads();
+    if (tid < nrows) {
+        float best = __builtin_inff();
+        int bestc = 0;
+        for (int c0 = 0; c0 < Cpad; c0 += CELL_TP) {
+            float acc[CELL_TP];
+#pragma unroll
+            for (int u = 0; u < CELL_TP; ++u) acc[u] = pn[c0 + u];
+            for (int i = 0; i < d; ++i) {
+                const float x2 = -2.0f * xT[i * (CELL_ROWS + 1) + tid];
+                const float4 pa = *reinterpret_cast<const float4*>(pT + i * Cpad + c0);
+                const float4 pb = *reinterpret_cast<const float4*>(pT + i * Cpad + c0 + 4);
+                acc[0] = __fmaf_rn(x2, pa.x, acc[0]); acc[1] = __fmaf_rn(x2, pa.y, acc[1]);
+                acc[2] = __fmaf_rn(x2, pa.z, acc[2]); acc[3] = __fmaf_rn(x2, pa.w, acc[3]);
+                acc[4] = __fmaf_rn(x2, pb.x, acc[4]); acc[5] = __fmaf_rn(x2, pb.y, acc[5]);
+                acc[6] = __fmaf_rn(x2, pb.z, acc[6]); acc[7] = __fmaf_rn(x2, pb.w, acc[7]);
+            }
+#pragma unroll
+            for (int u = 0; u < CELL_TP; ++u)
+                if (acc[u] < best) { best = acc[u]; bestc = c0 + u; }  // NaN rows stay in cell 0
+        }
+        if (bestc >= C) bestc = 0;
+        cell[row0 + tid] = (unsigned char)bestc;
+        atomicAdd(&hist[bestc], 1);
+    }
+    __syncthreads();
+    for (int i = tid; i < C; i += CELL_ROWS) blockhist[(long long)blockIdx.x * C + i] = hist[i];
+}
+
+// blockhist[b][c] -> rows of cell c in blocks before b; cell_start[c] = rows in cells before c
+// (cell_start[C] = n).  One block, one thread per cell.
+__global__ __launch_bounds__(256) void cell_offsets_kernel(int* __restrict__ blockhist, int nblk, int C,
+                                                           int* __restrict__ cell_start) {
+    __shared__ int tot[257];
+    const int c = threadIdx.x;
+    int run = 0;
+    if (c < C) {
+        for (int b = 0; b < nblk; ++b) {
+            const int v = blockhist[(long long)b * C + c];
+            blockhist[(long long)b * C + c] = run;
+            run += v;
+        }
+    }
+    tot[c] = c < C ? run : 0;
+    __syncthreads();
+    if (c == 0) {
+        int acc = 0;
+        for (int i = 0; i < C; ++i) { const int v = tot[i]; tot[i] = acc; acc += v; }
+        tot[C] = acc;
+    }
+    __syncthreads();
+    if (c <= C) cell_start[c] = tot[c];
+}
+
+// perm[position] = row: rows ordered by (cell, row number)
+__global__ __launch_bounds__(CELL_ROWS) void cell_scatter_kernel(const unsigned char* __restrict__ cell, long long n,
+                                                                 int C, const int* __restrict__ blockoff,
+                                                                 const int* __restrict__ cell_start,
+                                                                 int* __restrict__ perm) {
+    __shared__ unsigned char cs[CELL_ROWS];
+    const int tid = threadIdx.x;
+    const long long row = (long long)blockIdx.x * CELL_ROWS + tid;
+    cs[tid] = row < n ? cell[row] : 255;
+    __syncthreads();
+    if (row >= n) return;
+    const int mine = cs[tid];
+    int before = 0;
+    for (int t = 0; t < tid; ++t) before += (cs[t] == mine) ? 1 : 0;
+    perm[cell_start[mine] + blockoff[(long long)blockIdx.x * C + mine] + before] = (int)row;
+}
+
+// home[b] = {first stage, number of stages} of the reference rows that share a cell with
+// query block b's queries (at most max_stages of them)
+__global__ void home_stages_kernel(const unsigned char* __restrict__ qcell, const int* __restrict__ perm_q,
+                                   long long n, int qpb, int nqb, const int* __restrict__ rcell_start, int RT,
+                                   long long m_pad, int max_stages, int* __restrict__ home) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nqb) return;
+    const long long first = (long long)b * qpb;
+    long long last = first + qpb - 1;
+    if (last > n - 1) last = n - 1;
+    int s0 = 0, sn = 0;
+    if (first < n) {
+        const int c_lo = qcell[perm_q[first]], c_hi = qcell[perm_q[last]];
+        const long long r0 = rcell_start[c_lo], r1 = rcell_start[c_hi + 1];
+        s0 = (int)(r0 / RT);
+        long long s1 = (r1 + RT - 1) / RT;
+        if (s1 > s0 + max_stages) s1 = s0 + max_stages;
+        if (s1 > m_pad / RT) s1 = m_pad / RT;
+        sn = s1 > s0 ? (int)(s1 - s0) : 0;
+    }
+    home[2 * b] = s0;
+    home[2 * b + 1] = sn;
+}
+
+// Merge mode: a threshold to start from.  The running result's k-th distance D_k bounds what
+// this reference block can still contribute; in score space (score = D - |q|^2 up to the
+// rounding error the certificate knows) that is tau0, chosen so that the certificate's lower
+// bound for "score >= tau0" lies just above D_k.
+__global__ void seed_tau_kernel(const float* __restrict__ Q, const int* __restrict__ perm_q, int d, long long n,
+                                const int* __restrict__ idx, const float* __restrict__ d2, int k,
+                                double err_abs_coef, double rel_keep, const unsigned* __restrict__ maxnorm_bits,
+                                float* __restrict__ tau0) {
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    const long long qo = perm_q ? perm_q[q] : q;
+    float t0 = __uint_as_float(TAU_MAX_BITS);
+    if (idx[qo * k + k - 1] >= 0) {
+        const double Dk = (double)d2[qo * k + k - 1];
+        double qn = 0.0;
+        for (int i = 0; i < d; ++i) qn += (double)Q[qo * d + i] * (double)Q[qo * d + i];
+        const double rmax2 = (double)__uint_as_float(*maxnorm_bits) * (1.0 + 1e-5);
+        double t = Dk / rel_keep - qn + err_abs_coef * (rmax2 + qn);
+        t += (fabs(t) + Dk + qn) * 1e-6;
+        float f = (float)t;
+        if ((double)f < t) f = nextafterf(f, __builtin_inff());
+        if (f < t0) t0 = f;
+    }
+    tau0[q] = t0;
 }
 
 // --------------------------------------------------------------------------------
@@ -153,6 +332,9 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
     u64* __restrict__ lists,          // [S][n_pad][64], then the tail region's extra lists
     uint2* __restrict__ pend_g,       // [shortlists][PCAP] pending candidates (GP_ only)
     long long n, long long n_pad, int nqb, long long chunk_rows, FusedTail tail, int kt, int ablate_in,
+    const int* __restrict__ home,     // [nqb][2] home stages of every query block, or NULL
+    const float* __restrict__ tau0,   // [n_pad] threshold to start from, or NULL
+    float* __restrict__ tau_out,      // [shortlists] threshold each shortlist ended with
     u64* __restrict__ diag_out /* per wave 8 counters (DIAG_ instantiations only) */) {
     u64* const diag = DIAG_ ? diag_out : nullptr;  // compile-time NULL in the product kernel (may be NULL in the other too)
 #ifndef SCMIAC_ABL
@@ -204,6 +386,33 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
     }
     const long long q0 = (long long)qb * C::QPB + wave * 32;  // first query of this wave
     const int T = (int)(rows_here / RT);
+    // The order in which this block streams the reference stages (global stage g = rows
+    // g RT .. g RT + RT - 1 of the packed image).  Its queries' home stages [H0, H0 + HN) come
+    // first: those outside the block's own chunk only to tighten the thresholds (what they
+    // shortlist is dropped again: the block that owns them lists them), then those inside it,
+    // then the rest of the chunk.
+    const int G0 = (int)(r_begin / RT);
+    int H0 = 0, HN = 0;
+    if (home != nullptr && T > 0) { H0 = home[2 * qb]; HN = home[2 * qb + 1]; }
+    int O0 = H0 > G0 ? H0 : G0;                                  // home stages inside the chunk: [O0, O0 + oN)
+    const int O1 = (H0 + HN < G0 + T) ? H0 + HN : G0 + T;
+    const int oN = O1 > O0 ? O1 - O0 : 0;
+    if (oN == 0) O0 = G0;
+    const int aN = HN - oN;                                      // home stages outside it, streamed first
+    const int Ttot = T > 0 ? aN + T : 0;
+    auto stage_row = [=](int i) __attribute__((always_inline)) {  // first reference row of the i-th stage streamed
+        int g;
+        if (i < aN) {
+            g = H0 + i;
+            if (oN > 0 && g >= O0) g += oN;
+        } else if (i < aN + oN) {
+            g = O0 + (i - aN);
+        } else {
+            g = G0 + (i - aN - oN);
+            if (oN > 0 && g >= O0) g += oN;
+        }
+        return (long long)g * RT;
+    };
 
     constexpr int HCAP = PCAP / 2;  // each lane appends to a buffer of its own: no atomics
     uint2* pend_w = GP_ ? pend_g + list_row * PCAP : pend + wave * 32 * PCAP;
@@ -227,7 +436,9 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
     for (int c = 0; c < D2P; ++c) asm volatile("" : "+v"(qf[c]));
     // running threshold: score of the 64th best reference so far; padding queries take nothing
     const float tau_max = __uint_as_float(TAU_MAX_BITS);  // padding rows score exactly this
-    float tau = (q0 + j < n && !(ablate & 1)) ? tau_max : -__builtin_inff();
+    float tau_start = tau_max;
+    if (tau0 != nullptr) tau_start = fminf(tau0[q0 + j], tau_max);
+    float tau = (q0 + j < n && !(ablate & 1)) ? tau_start : -__builtin_inff();
     // The per-subtile test looks at raw scores; a key is within 16 ulp (2^-19 relative) of
     // its score, so "some key below tau" implies "some score below tau_hi".
     auto widen = [](float t) __attribute__((always_inline)) {
@@ -381,13 +592,27 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
 
 
     {   // Two stage buffers, one block barrier per stage.
-        if (T > 0) SCMIAC_STAGE(0, 0);
+        if (Ttot > 0) SCMIAC_STAGE(stage_row(0), 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        for (int t = 0; t < T; ++t) {
-            if (do_stage && t + 1 < T) SCMIAC_STAGE(t + 1, (t + 1) & 1);
+        for (int t = 0; t < Ttot; ++t) {
+            if (do_stage && t + 1 < Ttot) SCMIAC_STAGE(stage_row(t + 1), (t + 1) & 1);
+            if (__builtin_expect(aN > 0 && t == aN, 0)) {
+                // the home stages outside the chunk are done: their last subtile is still
+                // untested; then every pending candidate is merged (tightest thresholds) and the
+                // shortlists start again from nothing -- the thresholds stay
+                float mn_ = accs[1][0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) mn_ = fminf(mn_, accs[1][r]);
+                if (__any(mn_ < tau_hi)) select_slow(accs[1], ref0s[1]);
+                flush_full(false, false);
+                inited = 0u;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accs[1][r] = tau_max;
+            }
             const float* tb = tile + (do_stage ? (t & 1) : 0) * RT * LS;
             const float* nb = tnorm + (do_stage ? (t & 1) : 0) * RT;
+            const long long cur_row0 = stage_row(t);
             // |r|^2 and fragments of the stage's first subtile (the stage only became readable at
             // the barrier; set 0 was tested during the previous stage's last subtile)
             SCMIAC_LOAD_NORMS(0, 0);
@@ -416,13 +641,15 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
             if (do_sync) __syncthreads();
         }
     }
-    if (T > 0) {  // the last subtile is still untested
+    if (Ttot > 0) {  // the last subtile is still untested
         float mn_ = accs[1][0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) mn_ = fminf(mn_, accs[1][r]);
         if (__any(mn_ < tau_hi)) select_slow(accs[1], ref0s[1]);
     }
     flush_full(false, true);
+    // what the refine pass may assume of every reference this block streamed and did not list
+    if (hh == 0) tau_out[list_row + j] = tau;
     if (diag && lane == 0) {
         u64* o = diag + ((long long)blockIdx.x * NW + wave) * 12;
         o[0] = (u64)clock64() - dg_t0; o[1] = dg_slow; o[2] = dg_flush; o[3] = dg_nslow;
@@ -444,13 +671,17 @@ __global__ __launch_bounds__(256) void refine_kernel(
     double err_abs_coef,  // 2*G: |s + |q|^2 - T| <= err_abs_coef * (|r|^2 + |q|^2)
     double rel_keep,      // 1 - gamma: D >= T * rel_keep
     const unsigned* __restrict__ maxnorm_bits,
+    const float* __restrict__ tau_lists,  // [shortlists]: the threshold each list ended with
+    const int* __restrict__ perm_q,       // packed query position -> caller's row (NULL: the same)
+    const int* __restrict__ perm_r,       // packed reference row -> caller's row (NULL: the same)
     int* __restrict__ out_idx,
     float* __restrict__ out_d2, float* __restrict__ out_dist, double* __restrict__ lower_bound,
     int* __restrict__ fail_rows, int* __restrict__ n_fail) {
     const int lane = threadIdx.x & 63;
-    const long long q = (long long)blockIdx.x * (blockDim.x >> 6) +
-                        __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (q >= n) return;
+    const long long qp = (long long)blockIdx.x * (blockDim.x >> 6) +
+                         __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // position in the packed order
+    if (qp >= n) return;
+    const long long q = perm_q ? (long long)perm_q[qp] : qp;                 // the caller's row: outputs go there
     const float* qrow = Q + q * d;
 
     double qn = 0.0;
@@ -467,19 +698,23 @@ __global__ __launch_bounds__(256) void refine_kernel(
         lb = lower_bound[q];
     }
     const long long tail_q0 = (long long)tail.qb0 * tail.qpb;
-    const bool in_tail = q >= tail_q0;
+    const bool in_tail = qp >= tail_q0;
     const int S_q = in_tail ? tail.St : S;
     for (int s = 0; s < S_q; ++s) {
-        long long lrow = (long long)s * n_pad + q;
-        if (in_tail && s > 0) lrow = tail.lists_row0 + (long long)(s - 1) * tail.rows + (q - tail_q0);
+        long long lrow = (long long)s * n_pad + qp;
+        if (in_tail && s > 0) lrow = tail.lists_row0 + (long long)(s - 1) * tail.rows + (qp - tail_q0);
         u64 e = lists[lrow * 64 + lane];
         unsigned ridx = (unsigned)e;
-        float tau_s = ord2f(__builtin_amdgcn_readlane((unsigned)(e >> 32), kt - 1));
+        // every reference of this chunk outside the list scores at least this much; a threshold
+        // that never came down from its ceiling means the list holds all there was
+        float tau_s = tau_lists[lrow];
+        if (tau_s >= __uint_as_float(TAU_MAX_BITS)) tau_s = __builtin_inff();
         u64 key = KEY_SENTINEL;
         if (ridx != 0xffffffffu) {
-            float D = exact_dist2_packed(reinterpret_cast<const float4*>(Qp + q * rowf),
+            float D = exact_dist2_packed(reinterpret_cast<const float4*>(Qp + qp * rowf),
                                          reinterpret_cast<const float4*>(Rp + (long long)ridx * ls), rowf / 4);
-            key = ((u64)__float_as_uint(D) << 32) | (u64)(unsigned)(ridx + col_offset);
+            const long long rrow = perm_r ? (long long)perm_r[ridx] : (long long)ridx;
+            key = ((u64)__float_as_uint(D) << 32) | (u64)(unsigned)(rrow + col_offset);
         }
         key = wave_sort<64>(key, lane);
         u64 rev = __shfl(key, 63 - lane);
@@ -672,7 +907,8 @@ int knn_pick_d2(int d) {
 template <int D2, int NW, int RT, int PC, bool GP, bool DIAG>
 static hipError_t launch_fused_t(const float* Qp, const float* Rp, const float* rnorm, u64* lists, uint2* pend_g,
                                  long long n, long long n_pad, int nqb, int S, long long chunk_rows,
-                                 const FusedTail& tail, int kt, int ablate, u64* diag, hipStream_t stream) {
+                                 const FusedTail& tail, int kt, int ablate, const int* home, const float* tau0,
+                                 float* tau_out, u64* diag, hipStream_t stream) {
     using C = FusedCfg<D2, NW, RT, PC, GP>;
     size_t lds = C::lds_bytes();
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_knn_kernel<D2, NW, RT, PC, GP, DIAG>),
@@ -680,7 +916,7 @@ static hipError_t launch_fused_t(const float* Qp, const float* Rp, const float* 
     if (e != hipSuccess) return e;
     dim3 grid((unsigned)(tail.block0 + (nqb - tail.qb0) * tail.St)), block(NW * 64);
     hipLaunchKernelGGL((fused_knn_kernel<D2, NW, RT, PC, GP, DIAG>), grid, block, lds, stream, Qp, Rp, rnorm, lists, pend_g, n,
-                       n_pad, nqb, chunk_rows, tail, kt, ablate, diag);
+                       n_pad, nqb, chunk_rows, tail, kt, ablate, home, tau0, tau_out, diag);
     return hipGetLastError();
 }
 
@@ -778,6 +1014,16 @@ KnnGeometry knn_geometry(long long n, long long m, int d, int k, int splits) {
     g.ls = g.rowf + (((g.rowf / 4) % 2 == 0) ? 4 : 8);
     const FusedTuning tn = knn_get_tuning();
     fused_variant(g.D2, tn, &g.nw, &g.RT, &g.pcap, &g.gp);
+    // locality partition: worth its passes over both sets once the stream is long enough to have
+    // a candidate-dense start worth cutting; its kernels hold a block's rows and the pivots in LDS
+    g.cells = 0; g.cells_pad = 0; g.home_max = 0;
+    if (!tn.no_locality && d <= 64 && m >= 16384 && n >= 2048) {
+        long long c = m / 2048;
+        c = c < 8 ? 8 : (c > 248 ? 248 : c);
+        g.cells = (int)c;
+        g.cells_pad = (g.cells + 7) & ~7;
+        g.home_max = (8192 + g.RT - 1) / g.RT;  // a block streams at most this many home stages first
+    }
     g.qpb = g.nw * 32;
     g.n_pad = ((n + g.qpb - 1) / g.qpb) * g.qpb;
     g.nqb = (int)(g.n_pad / g.qpb);
@@ -860,16 +1106,66 @@ KnnGeometry knn_geometry(long long n, long long m, int d, int k, int splits) {
 }
 
 hipError_t launch_pack(const float* X, long long n, int d, const KnnGeometry& g, float scale, float* Xp,
-                       int ld, float* norms, long long n_pad, unsigned* maxnorm_bits, hipStream_t stream) {
+                       int ld, float* norms, long long n_pad, unsigned* maxnorm_bits, const int* perm,
+                       hipStream_t stream) {
     dim3 block(256), grid((unsigned)((n_pad + PACK_ROWS - 1) / PACK_ROWS));
     hipLaunchKernelGGL(pack_rows_kernel, grid, block, 0, stream, X, n, d, g.D2, g.D2P, scale, Xp, ld, norms,
-                       n_pad, maxnorm_bits);
+                       n_pad, maxnorm_bits, perm);
+    return hipGetLastError();
+}
+
+// One side of the locality partition: cell of every row of X (nearest pivot), the permutation
+// that orders the rows by (cell, row number) and the first position of every cell.
+static hipError_t launch_cells(const float* X, long long n, int d, const KnnGeometry& g, const float* pivT,
+                               const float* pnorm, unsigned char* cell, int* blockhist, int* cell_start, int* perm,
+                               hipStream_t stream) {
+    const int C = g.cells, Cpad = g.cells_pad;
+    const int nblk = (int)((n + CELL_ROWS - 1) / CELL_ROWS);
+    const size_t lds = sizeof(float) * ((size_t)d * Cpad + Cpad + (size_t)d * (CELL_ROWS + 1)) + sizeof(int) * Cpad;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&assign_cells_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(assign_cells_kernel, dim3((unsigned)nblk), dim3(CELL_ROWS), lds, stream, X, n, d, pivT, pnorm, C,
+                       Cpad, cell, blockhist);
+    hipLaunchKernelGGL(cell_offsets_kernel, dim3(1), dim3(256), 0, stream, blockhist, nblk, C, cell_start);
+    hipLaunchKernelGGL(cell_scatter_kernel, dim3((unsigned)nblk), dim3(CELL_ROWS), 0, stream, cell, n, C, blockhist,
+                       cell_start, perm);
+    return hipGetLastError();
+}
+
+hipError_t launch_locality(const float* Q, long long n, const float* R, long long m, int d, const KnnGeometry& g,
+                           const LocalityWs& w, hipStream_t stream) {
+    hipLaunchKernelGGL(pivots_kernel, dim3((unsigned)((g.cells_pad + 63) / 64)), dim3(64), 0, stream, R, m, d, g.cells,
+                       g.cells_pad, w.pivT, w.pnorm);
+    hipError_t e = launch_cells(R, m, d, g, w.pivT, w.pnorm, w.cell_r, w.hist_r, w.cstart_r, w.perm_r, stream);
+    if (e != hipSuccess) return e;
+    e = launch_cells(Q, n, d, g, w.pivT, w.pnorm, w.cell_q, w.hist_q, w.cstart_q, w.perm_q, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(home_stages_kernel, dim3((unsigned)((g.nqb + 63) / 64)), dim3(64), 0, stream, w.cell_q, w.perm_q,
+                       n, g.qpb, g.nqb, w.cstart_r, g.RT, g.m_pad, g.home_max, w.home);
+    return hipGetLastError();
+}
+
+// error model shared by the refine certificate and the merge-mode seed (see launch_refine)
+static void knn_error_model(int d, const KnnGeometry& g, double* err_abs_coef, double* rel_keep) {
+    const double u = 5.9604644775390625e-08;  // 2^-24
+    const double G = 2.0 * (double)(d + 2 * g.D2 + 4 + 32) * u;
+    *err_abs_coef = 2.0 * G;
+    *rel_keep = 1.0 - 2.0 * (double)(d + 4) * u;
+}
+
+hipError_t launch_seed_tau(const float* Q, const int* perm_q, int d, long long n, const KnnGeometry& g, const int* idx,
+                           const float* d2, int k, const unsigned* maxnorm_bits, float* tau0, hipStream_t stream) {
+    double coef, keep;
+    knn_error_model(d, g, &coef, &keep);
+    hipLaunchKernelGGL(seed_tau_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, Q, perm_q, d, n, idx, d2,
+                       k, coef, keep, maxnorm_bits, tau0);
     return hipGetLastError();
 }
 
 hipError_t launch_fused(const KnnGeometry& g, const float* Qp, const float* Rp, const float* rnorm,
-                        unsigned long long* lists, void* pend_g_, long long n, int kt,
-                        unsigned long long* diag, hipStream_t stream) {
+                        unsigned long long* lists, void* pend_g_, long long n, int kt, const int* home,
+                        const float* tau0, float* tau_out, unsigned long long* diag, hipStream_t stream) {
     uint2* pend_g = static_cast<uint2*>(pend_g_);
     // counters (diag) and ablations (tuning bits: 1 no selection, 2 no staging, 4 no barrier,
     // 8 empty candidate path, 16 candidate arithmetic only) live in a separate instantiation
@@ -877,8 +1173,8 @@ hipError_t launch_fused(const KnnGeometry& g, const float* Qp, const float* Rp, 
     const int ablate = knn_get_tuning().ablate;
 #define SCMIAC_FUSED_CASE(V_, NW_, RT_, PC_, GP_)                                                  \
     if (g.D2 == V_ && g.nw == NW_ && g.RT == RT_ && g.pcap == PC_ && g.gp == GP_)                  \
-        return (diag || ablate) ? launch_fused_t<V_, NW_, RT_, PC_, (GP_ != 0), true>(Qp, Rp, rnorm, lists, pend_g, n, g.n_pad, g.nqb, g.S, g.chunk_rows, g.tail, kt, ablate, diag, stream) \
-                    : launch_fused_t<V_, NW_, RT_, PC_, (GP_ != 0), false>(Qp, Rp, rnorm, lists, pend_g, n, g.n_pad, g.nqb, g.S, g.chunk_rows, g.tail, kt, 0, diag, stream);
+        return (diag || ablate) ? launch_fused_t<V_, NW_, RT_, PC_, (GP_ != 0), true>(Qp, Rp, rnorm, lists, pend_g, n, g.n_pad, g.nqb, g.S, g.chunk_rows, g.tail, kt, ablate, home, tau0, tau_out, diag, stream) \
+                    : launch_fused_t<V_, NW_, RT_, PC_, (GP_ != 0), false>(Qp, Rp, rnorm, lists, pend_g, n, g.n_pad, g.nqb, g.S, g.chunk_rows, g.tail, kt, 0, home, tau0, tau_out, diag, stream);
     SCMIAC_FUSED_VARIANTS(SCMIAC_FUSED_CASE)
     return hipErrorInvalidValue;
 #undef SCMIAC_FUSED_CASE
@@ -886,23 +1182,22 @@ hipError_t launch_fused(const KnnGeometry& g, const float* Qp, const float* Rp, 
 
 hipError_t launch_refine(const float* Q, const float* Qp, const float* Rp, int d, long long n, const KnnGeometry& g,
                          const unsigned long long* lists, int k, int kt, long long col_offset, int merge,
-                         const unsigned* maxnorm_bits, int* idx, float* d2, float* dist, double* lb,
-                         int* fail_rows, int* n_fail, hipStream_t stream) {
+                         const unsigned* maxnorm_bits, const float* tau_lists, const int* perm_q, const int* perm_r,
+                         int* idx, float* d2, float* dist, double* lb, int* fail_rows, int* n_fail,
+                         hipStream_t stream) {
     // rounding-error model of the fused score s against T = |q|^2 + |r|^2 - 2 q.r (exact),
     // with gamma_n = n u / (1 - n u), u = 2^-24: the MFMA chain (2*D2 products) and the norm
     // chain (d terms) are each a float32 inner product, so
     //   |s + |q|^2 - T| <= G (|r| + |q|)^2 <= 2 G (|r|^2 + |q|^2),  G = gamma_{d + 2*D2 + 1}
     //   D >= T (1 - gamma_{d+2})
     // both taken with a factor-two margin.
-    const double u = 5.9604644775390625e-08;  // 2^-24
-    // + 32 u: the selection key replaces the low four mantissa bits of the score
-    double G = 2.0 * (double)(d + 2 * g.D2 + 4 + 32) * u;
-    double err_abs_coef = 2.0 * G;
-    double rel_keep = 1.0 - 2.0 * (double)(d + 4) * u;
+    // (+ 32 u in G: the selection key replaces the low four mantissa bits of the score)
+    double err_abs_coef, rel_keep;
+    knn_error_model(d, g, &err_abs_coef, &rel_keep);
     dim3 block(256), grid((unsigned)((n + 3) / 4));
     hipLaunchKernelGGL(refine_kernel, grid, block, 0, stream, Q, Qp, Rp, g.rowf, g.ls, d, n, g.n_pad, lists, g.S, g.tail, k, kt,
-                       col_offset, merge, err_abs_coef, rel_keep, maxnorm_bits, idx, d2, dist, lb,
-                       fail_rows, n_fail);
+                       col_offset, merge, err_abs_coef, rel_keep, maxnorm_bits, tau_lists, perm_q, perm_r, idx, d2, dist,
+                       lb, fail_rows, n_fail);
     return hipGetLastError();
 }
 
