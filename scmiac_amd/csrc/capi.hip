@@ -191,6 +191,14 @@ int scmiac_knn_search(const float* q, int64_t n, const float* r, int64_t m, int 
         HIP_TRY(launch_seed_tau(q, w.loc.perm_q, d, n, g, idx, dist2, k, w.maxnorm, w.tau0, stream), "seed thresholds");
         tau0 = w.tau0;
     }
+    // thresholds from every query block's home rows (kernel variants other than the library's
+    // own choice have no seed kernel: they start cold)
+    if (g.cells > 0 && !knn_get_tuning().has_variant) {
+        HIP_TRY(launch_home_seed(g, w.qp, w.rp, w.rnorm, n, w.loc.home, knn_threshold_rank(k), tau0 != nullptr, w.tau0,
+                                 stream),
+                "home thresholds");
+        tau0 = w.tau0;
+    }
     int slot = -1;  // event pair of this search, when timing is on
     {
         std::lock_guard<std::mutex> lock(g_timing_mu);

@@ -87,6 +87,8 @@ hipError_t launch_pack(const float* X, long long n, int d, const KnnGeometry& g,
                        hipStream_t stream);
 hipError_t launch_locality(const float* Q, long long n, const float* R, long long m, int d, const KnnGeometry& g,
                            const LocalityWs& w, hipStream_t stream);
+hipError_t launch_home_seed(const KnnGeometry& g, const float* Qp, const float* Rp, const float* rnorm, long long n,
+                            const int* home, int kt, int combine, float* tau0, hipStream_t stream);
 hipError_t launch_seed_tau(const float* Q, const int* perm_q, int d, long long n, const KnnGeometry& g, const int* idx,
                            const float* d2, int k, const unsigned* maxnorm_bits, float* tau0, hipStream_t stream);
 hipError_t launch_fused(const KnnGeometry& g, const float* Qp, const float* Rp, const float* rnorm,

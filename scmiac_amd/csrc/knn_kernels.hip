@@ -386,11 +386,10 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
     }
     const long long q0 = (long long)qb * C::QPB + wave * 32;  // first query of this wave
     const int T = (int)(rows_here / RT);
-    // The order in which this block streams the reference stages (global stage g = rows
-    // g RT .. g RT + RT - 1 of the packed image).  Its queries' home stages [H0, H0 + HN) come
-    // first: those outside the block's own chunk only to tighten the thresholds (what they
-    // shortlist is dropped again: the block that owns them lists them), then those inside it,
-    // then the rest of the chunk.
+    // The order in which this block streams the reference stages of its chunk (global stage g =
+    // rows g RT .. g RT + RT - 1 of the packed image): the home stages of its queries that lie
+    // inside the chunk first -- their near neighbours, which bring the thresholds down to where
+    // they will stay -- then the rest.
     const int G0 = (int)(r_begin / RT);
     int H0 = 0, HN = 0;
     if (home != nullptr && T > 0) { H0 = home[2 * qb]; HN = home[2 * qb + 1]; }
@@ -398,22 +397,16 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
     const int O1 = (H0 + HN < G0 + T) ? H0 + HN : G0 + T;
     const int oN = O1 > O0 ? O1 - O0 : 0;
     if (oN == 0) O0 = G0;
-    const int aN = HN - oN;                                      // home stages outside it, streamed first
-    const int Ttot = T > 0 ? aN + T : 0;
     auto stage_row = [=](int i) __attribute__((always_inline)) {  // first reference row of the i-th stage streamed
         int g;
-        if (i < aN) {
-            g = H0 + i;
-            if (oN > 0 && g >= O0) g += oN;
-        } else if (i < aN + oN) {
-            g = O0 + (i - aN);
+        if (i < oN) {
+            g = O0 + i;
         } else {
-            g = G0 + (i - aN - oN);
-            if (oN > 0 && g >= O0) g += oN;
+            g = G0 + (i - oN);
+            if (g >= O0) g += oN;
         }
         return (long long)g * RT;
     };
-
     constexpr int HCAP = PCAP / 2;  // each lane appends to a buffer of its own: no atomics
     uint2* pend_w = GP_ ? pend_g + list_row * PCAP : pend + wave * 32 * PCAP;
     uint2* pend_l = pend_w + (j * 2 + hh) * HCAP;  // this lane's buffer: query j, lane half hh
@@ -592,24 +585,11 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
 
 
     {   // Two stage buffers, one block barrier per stage.
-        if (Ttot > 0) SCMIAC_STAGE(stage_row(0), 0);
+        if (T > 0) SCMIAC_STAGE(stage_row(0), 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        for (int t = 0; t < Ttot; ++t) {
-            if (do_stage && t + 1 < Ttot) SCMIAC_STAGE(stage_row(t + 1), (t + 1) & 1);
-            if (__builtin_expect(aN > 0 && t == aN, 0)) {
-                // the home stages outside the chunk are done: their last subtile is still
-                // untested; then every pending candidate is merged (tightest thresholds) and the
-                // shortlists start again from nothing -- the thresholds stay
-                float mn_ = accs[1][0];
-#pragma unroll
-                for (int r = 1; r < 16; ++r) mn_ = fminf(mn_, accs[1][r]);
-                if (__any(mn_ < tau_hi)) select_slow(accs[1], ref0s[1]);
-                flush_full(false, false);
-                inited = 0u;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) accs[1][r] = tau_max;
-            }
+        for (int t = 0; t < T; ++t) {
+            if (do_stage && t + 1 < T) SCMIAC_STAGE(stage_row(t + 1), (t + 1) & 1);
             const float* tb = tile + (do_stage ? (t & 1) : 0) * RT * LS;
             const float* nb = tnorm + (do_stage ? (t & 1) : 0) * RT;
             const long long cur_row0 = stage_row(t);
@@ -641,7 +621,7 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
             if (do_sync) __syncthreads();
         }
     }
-    if (Ttot > 0) {  // the last subtile is still untested
+    if (T > 0) {  // the last subtile is still untested
         float mn_ = accs[1][0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) mn_ = fminf(mn_, accs[1][r]);
@@ -657,6 +637,145 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
         o[8] = dg_seg2; o[9] = dg_ngen; o[10] = 0; o[11] = 0;
     }
 }
+
+#undef SCMIAC_TEST_PREV
+
+// --------------------------------------------------------------------------------
+// home_seed: a threshold for every query before the search starts.  Block b streams only the
+// home stages of query block b (same MFMA stage loop, no selection at all): every lane keeps
+// the running minimum of each of its 16 accumulator registers, separately for even and odd
+// subtiles, so a query ends up with 64 minima over 64 DISJOINT sets of home rows.  The kt-th
+// smallest of them has at least kt rows scoring no more than itself: an upper bound of the
+// query's kt-th smallest score over all references, typically the ~50th smallest score of the
+// home rows.  The search then starts from it instead of from "everything passes", which
+// removes the cold start (hundreds of candidates and half a dozen merges per query).
+// --------------------------------------------------------------------------------
+// (not inlined: inlined into the kernel below, whose stage loop carries scheduling directives,
+// this network sent the compiler into a pass that did not finish within an hour)
+__device__ __attribute__((noinline)) unsigned wave_sort_u32(unsigned v, int lane) {
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const unsigned o = (unsigned)__shfl_xor((int)v, j);
+            const bool up = (lane & k) == 0, low = (lane & j) == 0;
+            v = (up == low) ? (v < o ? v : o) : (v < o ? o : v);
+        }
+    }
+    return v;
+}
+
+#define SCMIAC_TEST_PREV(PRV_)                                                                      \
+    do {                                                                                            \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) gmin[PRV_][r] = fminf(gmin[PRV_][r], accs[PRV_][r]); \
+    } while (0)
+
+template <int D2, int NW_, int RT_>
+__global__ __launch_bounds__(NW_ * 64, (NW_ >= 8 ? NW_ / 4 : 2)) void home_seed_kernel(
+    const float* __restrict__ Qp, const float* __restrict__ Rp, const float* __restrict__ rnorm, long long n,
+    const int* __restrict__ home, int kt, int combine, float* __restrict__ tau0) {
+    using C = FusedCfg<D2, NW_, RT_, 32, true>;
+    constexpr int D2P = C::D2P, ROWF = C::ROWF, LS = C::LS, RT = C::RT, NW = C::NW;
+    constexpr int NSUB = RT / 32, NB = C::NB;
+    constexpr int STAGE_BYTES = RT * LS * 4;
+    constexpr int NCHUNK = STAGE_BYTES / 1024;
+    constexpr int LD_ITERS = (NCHUNK + NW - 1) / NW;
+    constexpr int NORM_CHUNKS = RT / 64;
+    static_assert(STAGE_BYTES % 1024 == 0 && RT % 64 == 0 && NORM_CHUNKS <= NW, "stage geometry");
+    // (the launcher sizes the dynamic LDS to hold every wave's 32 x 64 minima afterwards as well)
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* tile = reinterpret_cast<float*>(smem);  // [NB][RT*LS]
+    float* tnorm = tile + NB * RT * LS;            // [NB][RT]
+    const unsigned tile_lds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)tile;
+    const unsigned tnorm_lds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)tnorm;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, hh = lane >> 5;
+    const int qb = blockIdx.x;
+    const long long q0 = (long long)qb * C::QPB + wave * 32;
+    const int H0 = home[2 * qb], T = home[2 * qb + 1];
+    const float big = __uint_as_float(TAU_MAX_BITS);
+
+    float qf[D2P];
+    {
+        const float4* qp4 = reinterpret_cast<const float4*>(Qp + (q0 + j) * ROWF + hh * D2P);
+#pragma unroll
+        for (int c = 0; c < D2P / 4; ++c) {
+            float4 v = qp4[c];
+            qf[4 * c + 0] = v.x; qf[4 * c + 1] = v.y; qf[4 * c + 2] = v.z; qf[4 * c + 3] = v.w;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < D2P; ++c) asm volatile("" : "+v"(qf[c]));
+
+    constexpr int NGRP = D2P / 4;
+    static_assert(NGRP >= 2, "two groups of lookahead");
+    f32x16 accs[2];
+    float fr[3][4];
+    unsigned ref0s[2] = {0u, 0u};
+    float gmin[2][16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { accs[1][r] = big; gmin[0][r] = big; gmin[1][r] = big; }
+
+    if (T > 0) SCMIAC_STAGE((long long)H0 * RT, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        if (t + 1 < T) SCMIAC_STAGE((long long)(H0 + t + 1) * RT, (t + 1) & 1);
+        const float* tb = tile + (t & 1) * RT * LS;
+        const float* nb = tnorm + (t & 1) * RT;
+        const long long cur_row0 = (long long)(H0 + t) * RT;
+        SCMIAC_LOAD_NORMS(0, 0);
+        SCMIAC_LOAD_GROUP(0, 0, 0);
+        SCMIAC_LOAD_GROUP(0, 1, 1);
+        static_assert(NSUB == 2 || NSUB == 4 || NSUB == 8 || NSUB == 10, "stage of 64, 128, 256 or 320 rows");
+        SCMIAC_SUBTILE(0, 1, 0);
+        SCMIAC_SUBTILE(1, 0, 1);
+        if constexpr (NSUB > 2) {
+            SCMIAC_SUBTILE(0, 1, 2);
+            SCMIAC_SUBTILE(1, 0, 3);
+        }
+        if constexpr (NSUB > 4) {
+            SCMIAC_SUBTILE(0, 1, 4);
+            SCMIAC_SUBTILE(1, 0, 5);
+            SCMIAC_SUBTILE(0, 1, 6);
+            SCMIAC_SUBTILE(1, 0, 7);
+        }
+        if constexpr (NSUB > 8) {
+            SCMIAC_SUBTILE(0, 1, 8);
+            SCMIAC_SUBTILE(1, 0, 9);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    (void)ref0s;
+    if (T > 0) SCMIAC_TEST_PREV(1);  // the last subtile
+    // every wave has passed the last barrier: the stage buffers are free.  This wave's slice:
+    // [query 0..31][64 minima]; lane (j, hh) holds minima hh*32 .. hh*32+31 of query j
+    float* mine = tile + wave * (32 * 64);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mine[j * 64 + hh * 32 + s * 16 + r] = gmin[s][r];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    float out = big;
+#pragma clang loop unroll(disable)
+    for (int q = 0; q < 32; ++q) {
+        const unsigned v = wave_sort_u32(f2ord(mine[q * 64 + lane]), lane);
+        const float kth = ord2f((unsigned)__shfl((int)v, kt - 1));
+        if (j == q) out = kth;
+    }
+    if (hh == 0 && q0 + j < n) {
+        // the search compares keys (scores with four replaced mantissa bits): widen like tau_hi
+        float t = out < big ? out + fabsf(out) * 3.814697265625e-06f + 1e-30f : big;
+        if (combine) t = fminf(t, tau0[q0 + j]);
+        tau0[q0 + j] = t;
+    }
+}
+#undef SCMIAC_TEST_PREV
 
 // --------------------------------------------------------------------------------
 // refine: one wave per query.  Exact D for the shortlisted references (oracle
@@ -1152,6 +1271,33 @@ static void knn_error_model(int d, const KnnGeometry& g, double* err_abs_coef, d
     const double G = 2.0 * (double)(d + 2 * g.D2 + 4 + 32) * u;
     *err_abs_coef = 2.0 * G;
     *rel_keep = 1.0 - 2.0 * (double)(d + 4) * u;
+}
+
+template <int D2, int NW, int RT>
+static hipError_t launch_home_seed_t(const float* Qp, const float* Rp, const float* rnorm, long long n, int nqb,
+                                     const int* home, int kt, int combine, float* tau0, hipStream_t stream) {
+    using C = FusedCfg<D2, NW, RT, 32, true>;
+    const size_t minima = sizeof(float) * NW * 32 * 64;
+    const size_t lds = C::lds_bytes() > minima ? C::lds_bytes() : minima;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&home_seed_kernel<D2, NW, RT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((home_seed_kernel<D2, NW, RT>), dim3((unsigned)nqb), dim3(NW * 64), lds, stream, Qp, Rp, rnorm, n,
+                       home, kt, combine, tau0);
+    return hipGetLastError();
+}
+
+// thresholds from the home rows (tau0[q] = that bound, or the smaller of it and what tau0 holds)
+hipError_t launch_home_seed(const KnnGeometry& g, const float* Qp, const float* Rp, const float* rnorm, long long n,
+                            const int* home, int kt, int combine, float* tau0, hipStream_t stream) {
+#define SCMIAC_SEED_CASE(V_, NW_, RT_) \
+    if (g.D2 == V_ && g.nw == NW_ && g.RT == RT_) \
+        return launch_home_seed_t<V_, NW_, RT_>(Qp, Rp, rnorm, n, g.nqb, home, kt, combine, tau0, stream);
+    // the feature sizes the locality partition serves (d <= 64), in the library's own variants
+    SCMIAC_SEED_CASE(8, 12, 320) SCMIAC_SEED_CASE(15, 12, 320) SCMIAC_SEED_CASE(16, 12, 320)
+    SCMIAC_SEED_CASE(20, 12, 320) SCMIAC_SEED_CASE(25, 12, 320) SCMIAC_SEED_CASE(32, 12, 256)
+#undef SCMIAC_SEED_CASE
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_seed_tau(const float* Q, const int* perm_q, int d, long long n, const KnnGeometry& g, const int* idx,
