@@ -78,8 +78,8 @@ static KnnWs knn_carve(void* ws, long long n, long long m, int d, const KnnGeome
         w.loc.cell_r = take((size_t)m);
         w.loc.hist_q = reinterpret_cast<int*>(take(sizeof(int) * nbq * g.cells));
         w.loc.hist_r = reinterpret_cast<int*>(take(sizeof(int) * nbr * g.cells));
-        w.loc.cstart_q = reinterpret_cast<int*>(take(sizeof(int) * (size_t)(g.cells + 1)));
-        w.loc.cstart_r = reinterpret_cast<int*>(take(sizeof(int) * (size_t)(g.cells + 1)));
+        w.loc.cstart_q = reinterpret_cast<int*>(take(sizeof(int) * 2 * (size_t)(g.cells + 1)));  // starts, then totals
+        w.loc.cstart_r = reinterpret_cast<int*>(take(sizeof(int) * 2 * (size_t)(g.cells + 1)));
         w.loc.perm_q = reinterpret_cast<int*>(take(sizeof(int) * (size_t)n));
         w.loc.perm_r = reinterpret_cast<int*>(take(sizeof(int) * (size_t)m));
         w.loc.home = reinterpret_cast<int*>(take(sizeof(int) * 2 * (size_t)g.nqb));
@@ -189,14 +189,6 @@ int scmiac_knn_search(const float* q, int64_t n, const float* r, int64_t m, int 
     const float* tau0 = nullptr;
     if (merge && m > 0) {
         HIP_TRY(launch_seed_tau(q, w.loc.perm_q, d, n, g, idx, dist2, k, w.maxnorm, w.tau0, stream), "seed thresholds");
-        tau0 = w.tau0;
-    }
-    // thresholds from every query block's home rows (kernel variants other than the library's
-    // own choice have no seed kernel: they start cold)
-    if (g.cells > 0 && !knn_get_tuning().has_variant) {
-        HIP_TRY(launch_home_seed(g, w.qp, w.rp, w.rnorm, n, w.loc.home, knn_threshold_rank(k), tau0 != nullptr, w.tau0,
-                                 stream),
-                "home thresholds");
         tau0 = w.tau0;
     }
     int slot = -1;  // event pair of this search, when timing is on

@@ -221,11 +221,12 @@ __device__ __forceinline__ float exact_dist2_packed(const float4* __restrict__ q
         if (4 * (G_) + 4 <= D2) __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                  \
         else __builtin_amdgcn_sched_group_barrier(0x008, (D2 % 4) ? (D2 % 4) : 4, 0);               \
     } while (0)
-#define SCMIAC_SUBTILE(CUR_, PRV_, SUB_)                                                            \
+// TEST_ names the macro that deals with the finished scores in accs[PRV_].
+#define SCMIAC_SUBTILE_T(CUR_, PRV_, SUB_, TEST_)                                                   \
     do {                                                                                            \
         SCMIAC_GROUP(CUR_, SUB_, 0);                                                                \
         {                                                                                           \
-            SCMIAC_TEST_PREV(PRV_);                                                                 \
+            TEST_(PRV_);                                                                            \
             if ((SUB_) + 1 < NSUB) {                                                                \
                 SCMIAC_LOAD_NORMS(PRV_, (SUB_) + 1);                                                \
                 __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                  \
@@ -233,6 +234,29 @@ __device__ __forceinline__ float exact_dist2_packed(const float4* __restrict__ q
         }                                                                                           \
         _Pragma("unroll") for (int g = 1; g < NGRP; ++g) SCMIAC_GROUP(CUR_, SUB_, g);               \
         ref0s[CUR_] = (unsigned)(cur_row0 + (SUB_) * 32); /* wave-uniform */                        \
+    } while (0)
+#define SCMIAC_SUBTILE(CUR_, PRV_, SUB_) SCMIAC_SUBTILE_T(CUR_, PRV_, SUB_, SCMIAC_TEST_PREV)
+// the subtiles of a stage, written out: their numbers must be compile-time constants (ring
+// slots, LDS offsets), whatever the optimizer thinks of unrolling a loop this big
+#define SCMIAC_STAGE_SUBTILES(TEST_)                                                                \
+    do {                                                                                            \
+        static_assert(NSUB == 2 || NSUB == 4 || NSUB == 8 || NSUB == 10, "stage of 64, 128, 256 or 320 rows"); \
+        SCMIAC_SUBTILE_T(0, 1, 0, TEST_);                                                           \
+        SCMIAC_SUBTILE_T(1, 0, 1, TEST_);                                                           \
+        if constexpr (NSUB > 2) {                                                                   \
+            SCMIAC_SUBTILE_T(0, 1, 2, TEST_);                                                       \
+            SCMIAC_SUBTILE_T(1, 0, 3, TEST_);                                                       \
+        }                                                                                           \
+        if constexpr (NSUB > 4) {                                                                   \
+            SCMIAC_SUBTILE_T(0, 1, 4, TEST_);                                                       \
+            SCMIAC_SUBTILE_T(1, 0, 5, TEST_);                                                       \
+            SCMIAC_SUBTILE_T(0, 1, 6, TEST_);                                                       \
+            SCMIAC_SUBTILE_T(1, 0, 7, TEST_);                                                       \
+        }                                                                                           \
+        if constexpr (NSUB > 8) {                                                                   \
+            SCMIAC_SUBTILE_T(0, 1, 8, TEST_);                                                       \
+            SCMIAC_SUBTILE_T(1, 0, 9, TEST_);                                                       \
+        }                                                                                           \
     } while (0)
 
 }  // namespace scmiac

@@ -45,6 +45,7 @@ struct KnnGeometry {
     int cells;             // pivots of the locality partition (0: rows keep the caller's order)
     int cells_pad;         // cells rounded up to a multiple of 8
     int home_max;          // most home stages a query block streams ahead of its chunk
+    int seed_stages;       // home stages the fused kernel's seed pass looks at
 };
 
 // device scratch of the locality partition (carved out of the search workspace)
@@ -55,8 +56,8 @@ struct LocalityWs {
     unsigned char* cell_r;  // [m]
     int* hist_q;            // [ceil(n / 256)][cells]
     int* hist_r;            // [ceil(m / 256)][cells]
-    int* cstart_q;          // [cells + 1]
-    int* cstart_r;          // [cells + 1]
+    int* cstart_q;          // [2 (cells + 1)]: first position of every cell, then scratch for the cell sizes
+    int* cstart_r;          // [2 (cells + 1)]
     int* perm_q;            // [n]: packed query position -> caller's row
     int* perm_r;            // [m]: packed reference row -> caller's row
     int* home;              // [nqb][2]
@@ -87,8 +88,6 @@ hipError_t launch_pack(const float* X, long long n, int d, const KnnGeometry& g,
                        hipStream_t stream);
 hipError_t launch_locality(const float* Q, long long n, const float* R, long long m, int d, const KnnGeometry& g,
                            const LocalityWs& w, hipStream_t stream);
-hipError_t launch_home_seed(const KnnGeometry& g, const float* Qp, const float* Rp, const float* rnorm, long long n,
-                            const int* home, int kt, int combine, float* tau0, hipStream_t stream);
 hipError_t launch_seed_tau(const float* Q, const int* perm_q, int d, long long n, const KnnGeometry& g, const int* idx,
                            const float* d2, int k, const unsigned* maxnorm_bits, float* tau0, hipStream_t stream);
 hipError_t launch_fused(const KnnGeometry& g, const float* Qp, const float* Rp, const float* rnorm,

@@ -165,29 +165,40 @@ __global__ __launch_bounds__(CELL_ROWS) void assign_cells_kernel(const float* __
     for (int i = tid; i < C; i += CELL_ROWS) blockhist[(long long)blockIdx.x * C + i] = hist[i];
 }
 
-// blockhist[b][c] -> rows of cell c in blocks before b; cell_start[c] = rows in cells before c
-// (cell_start[C] = n).  One block, one thread per cell.
-__global__ __launch_bounds__(256) void cell_offsets_kernel(int* __restrict__ blockhist, int nblk, int C,
-                                                           int* __restrict__ cell_start) {
-    __shared__ int tot[257];
-    const int c = threadIdx.x;
-    int run = 0;
-    if (c < C) {
-        for (int b = 0; b < nblk; ++b) {
-            const int v = blockhist[(long long)b * C + c];
-            blockhist[(long long)b * C + c] = run;
-            run += v;
-        }
-    }
-    tot[c] = c < C ? run : 0;
+// blockhist[b][c] -> rows of cell c in blocks before b (one block per cell scans its column);
+// col_total[c] = rows in cell c
+__global__ __launch_bounds__(256) void cell_column_scan_kernel(int* __restrict__ blockhist, int nblk, int C,
+                                                               int* __restrict__ col_total) {
+    __shared__ int part[256];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    const int per = (nblk + 255) / 256;
+    const int b0 = tid * per, b1 = (b0 + per < nblk) ? b0 + per : nblk;
+    int sum = 0;
+    for (int b = b0; b < b1; ++b) sum += blockhist[(long long)b * C + c];
+    part[tid] = sum;
     __syncthreads();
-    if (c == 0) {
+    for (int o = 1; o < 256; o <<= 1) {
+        const int t = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += t;
+        __syncthreads();
+    }
+    int run = part[tid] - sum;  // rows of this cell in the blocks before b0
+    for (int b = b0; b < b1; ++b) {
+        const int v = blockhist[(long long)b * C + c];
+        blockhist[(long long)b * C + c] = run;
+        run += v;
+    }
+    if (tid == 255) col_total[c] = part[255];
+}
+
+// cell_start[c] = rows in cells before c (cell_start[C] = all rows); C is at most a few hundred
+__global__ void cell_starts_kernel(const int* __restrict__ col_total, int C, int* __restrict__ cell_start) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
         int acc = 0;
-        for (int i = 0; i < C; ++i) { const int v = tot[i]; tot[i] = acc; acc += v; }
-        tot[C] = acc;
+        for (int c = 0; c < C; ++c) { cell_start[c] = acc; acc += col_total[c]; }
+        cell_start[C] = acc;
     }
-    __syncthreads();
-    if (c <= C) cell_start[c] = tot[c];
 }
 
 // perm[position] = row: rows ordered by (cell, row number)
@@ -321,6 +332,31 @@ __device__ __forceinline__ float flush_query(unsigned c0, unsigned c1, const uin
             if (__builtin_expect(__any(mn_ < tau_hi), 0)) select_slow(accs[PRV_], ref0s[PRV_]);     \
     } while (0)
 
+// ... and during the seed pass over the home stages: running minimum of every accumulator
+// register, even and odd subtiles apart (the accumulator set is the subtile's parity)
+#define SCMIAC_SEED_PREV(PRV_)                                                                      \
+    do {                                                                                            \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) gmin[PRV_][r] = fminf(gmin[PRV_][r], accs[PRV_][r]); \
+    } while (0)
+
+// ascending sort of 32 registers (bitonic network, every index a compile-time constant)
+__device__ __forceinline__ void sort32_regs(float (&v)[32]) {
+#pragma unroll
+    for (int k = 2; k <= 32; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const float lo = fminf(v[i], v[p]), hi = fmaxf(v[i], v[p]);
+                    if ((i & k) == 0) { v[i] = lo; v[p] = hi; } else { v[i] = hi; v[p] = lo; }
+                }
+            }
+        }
+    }
+}
+
 template <int D2, int NW_, int RT_, int PCAP_, bool GP_, bool DIAG_>
 __global__ __launch_bounds__(NW_ * 64, (NW_ >= 8 ? NW_ / 4 : 2))
 // exactly this many waves per SIMD: the LDS allows one block per CU, so registers saved
@@ -333,6 +369,7 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
     uint2* __restrict__ pend_g,       // [shortlists][PCAP] pending candidates (GP_ only)
     long long n, long long n_pad, int nqb, long long chunk_rows, FusedTail tail, int kt, int ablate_in,
     const int* __restrict__ home,     // [nqb][2] home stages of every query block, or NULL
+    int seed_stages,                  // most home stages the seed pass looks at
     const float* __restrict__ tau0,   // [n_pad] threshold to start from, or NULL
     float* __restrict__ tau_out,      // [shortlists] threshold each shortlist ended with
     u64* __restrict__ diag_out /* per wave 8 counters (DIAG_ instantiations only) */) {
@@ -471,8 +508,8 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
         if (diag) dg_flush += (u64)clock64() - tf0;
     };
 
-    // Candidate path (entered when some lane's smallest score is below its threshold).
-    // Register by register: the lanes whose key passes append it to their own buffer.  Every
+    // Candidate path (entered when some lane's smallest score is below its threshold): the
+    // lanes whose keys pass append them to their own buffer.  Every
     // step that depends on the one before costs a wave hundreds of cycles while its SIMD
     // partners keep the MFMA pipe busy, so the path is kept shallow: no cross-lane
     // traffic, no atomics, no search for minima.
@@ -496,38 +533,41 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
         const float a2 = min3_raw(key[6], key[7], key[8]), a3 = min3_raw(key[9], key[10], key[11]);
         const float a4 = min3_raw(key[12], key[13], key[14]);
         const float kmin = min2_raw(min3_raw(a0, a1, a2), min3_raw(a3, a4, key[15]));
-        // does any lane have two keys below its threshold?  Scalar bookkeeping on the compare
-        // masks, four registers at a time and then across the four groups: a single chain
-        // over all sixteen would be 32 scalar instructions each waiting for the one before.
-        u64 seen = 0ull, twice = 0ull;
+        // which of the lane's 16 keys pass: one bit each, gathered by a shallow tree
+        unsigned bit[16];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const u64 ma = __ballot(key[4 * g + 0] < tau), mb = __ballot(key[4 * g + 1] < tau);
-            const u64 mc = __ballot(key[4 * g + 2] < tau), md = __ballot(key[4 * g + 3] < tau);
-            const u64 sab = ma | mb, scd = mc | md;
-            const u64 sg = sab | scd;
-            const u64 tg = (ma & mb) | (mc & md) | (sab & scd);
-            twice |= tg | (seen & sg);
-            seen |= sg;
-        }
+        for (int r = 0; r < 16; ++r) bit[r] = (key[r] < tau) ? (1u << r) : 0u;
+        const unsigned m0 = bit[0] | bit[1] | bit[2], m1 = bit[3] | bit[4] | bit[5], m2 = bit[6] | bit[7] | bit[8];
+        const unsigned m3 = bit[9] | bit[10] | bit[11], m4 = bit[12] | bit[13] | bit[14];
+        const unsigned mask = (m0 | m1 | m2) | (m3 | m4 | bit[15]);
+        const unsigned cnt = (unsigned)__builtin_popcount(mask);
         const u64 ts1 = diag ? (u64)clock64() : 0;
-        if (diag) dg_seg1 += ts1 - ts0;  // keys, smallest key, duplicate check
+        if (diag) dg_seg1 += ts1 - ts0;  // keys and pass mask
         if (ablate & 16) {  // diagnostic: price of the arithmetic above without any store
-            asm volatile("" ::"v"(kmin), "s"(twice));
+            asm volatile("" ::"v"(mask), "v"(kmin));
             return;
         }
-        if (__builtin_expect(twice == 0ull, 1)) {
-            // the usual case: at most one candidate per lane, and it is the lane's smallest key
-            // (key register r holds subtile row (r & 3) + 8 (r >> 2) = r + (r & 12))
-            const unsigned kb = __float_as_uint(kmin);
-            const uint2 entry = make_uint2(kb, ref0 + (kb & 15u) + (kb & 12u));
-            // there is room: a buffer is merged as soon as it fills up (end of this path)
-            const bool p = kmin < tau;
-            if (p) pend_l[pcnt] = entry;
-            pcnt += p ? 1u : 0u;
-            if (diag) { ++dg_iters; dg_npush += __popcll(__ballot(p)); dg_seg2 += (u64)clock64() - ts1; }
+        if (__builtin_expect(!__any(pcnt + cnt > (unsigned)HCAP), 1)) {
+            // every lane has room for all its candidates
+            if (!__any(cnt > 1u)) {
+                // at most one per lane, and then it is the lane's smallest key, which names its own
+                // register (key register r holds subtile row (r & 3) + 8 (r >> 2) = r + (r & 12))
+                const unsigned kb = __float_as_uint(kmin);
+                if (cnt) pend_l[pcnt] = make_uint2(kb, ref0 + (kb & 15u) + (kb & 12u));
+            } else {
+                // sixteen independent predicated stores, each to the slot its rank among the lane's
+                // passing keys gives it
+                if (diag) ++dg_ngen;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned pos = pcnt + (unsigned)__builtin_popcount(mask & ((1u << r) - 1u));
+                    if (mask & (1u << r))
+                        pend_l[pos] = make_uint2(__float_as_uint(key[r]), ref0 + (unsigned)((r & 3) + 8 * (r >> 2)));
+                }
+            }
+            pcnt += cnt;
+            if (diag) { ++dg_iters; dg_npush += __popcll(__ballot(cnt > 0u)); dg_seg2 += (u64)clock64() - ts1; }
         } else {
-            if (diag) ++dg_ngen;
             unsigned skipped = 0u;  // bit r: key[r] passed but this lane's buffer was full
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -584,6 +624,57 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
     const bool do_sync = !(ablate & 4);   // diagnostic: no block barrier (results are garbage)
 
 
+    // Seed pass.  Before anything is selected the block streams (some of) its queries' home
+    // stages once with no selection at all: every lane keeps the running minimum of each of its
+    // 16 accumulator registers, even and odd subtiles apart -- 32 minima over 32 DISJOINT sets
+    // of home rows per lane, 64 per query.  If v is the 18th smallest of a lane's 32, at least
+    // 18 rows of that lane half score no more than v; with the other lane half's v, at least
+    // 36 >= kt rows score no more than the larger of the two: an upper bound of the query's
+    // kt-th smallest score, typically near the 60th smallest score of the rows looked at.  The
+    // search starts from it instead of from "everything passes", which removes the cold start
+    // (hundreds of candidates and half a dozen merges per query).
+    if (home != nullptr && T > 0 && !(ablate & 32)) {
+        const int SN = HN < seed_stages ? HN : seed_stages;
+        float gmin[2][16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { gmin[0][r] = tau_max; gmin[1][r] = tau_max; }
+        if (SN > 0) SCMIAC_STAGE((long long)H0 * RT, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int t = 0; t < SN; ++t) {
+            if (t + 1 < SN) SCMIAC_STAGE((long long)(H0 + t + 1) * RT, (t + 1) & 1);
+            const float* tb = tile + (t & 1) * RT * LS;
+            const float* nb = tnorm + (t & 1) * RT;
+            const long long cur_row0 = (long long)(H0 + t) * RT;
+            SCMIAC_LOAD_NORMS(0, 0);
+            SCMIAC_LOAD_GROUP(0, 0, 0);
+            SCMIAC_LOAD_GROUP(0, 1, 1);
+            SCMIAC_STAGE_SUBTILES(SCMIAC_SEED_PREV);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        if (SN > 0) {
+            SCMIAC_SEED_PREV(1);  // the last subtile
+            float all[32];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { all[r] = gmin[0][r]; all[16 + r] = gmin[1][r]; }
+            sort32_regs(all);
+            static_assert(SCMIAC_KNN_MAX_K_INTERNAL <= 64, "half of kt fits a lane half's 32 minima");
+            // the (kt / 2 rounded up)-th smallest of each lane half, the larger of the two halves
+            float mine = all[0];
+            const int need = (kt + 1) / 2;  // 1..32, wave-uniform
+#pragma unroll
+            for (int i = 1; i < 32; ++i) mine = (i < need) ? all[i] : mine;
+            const float other = __shfl_xor(mine, 32);
+            float bound = fmaxf(mine, other);
+            // the search compares keys (scores with four replaced mantissa bits): widen like tau_hi
+            bound = bound < tau_max ? widen(bound) : tau_max;
+            if (q0 + j < n && !(ablate & 1)) { tau = fminf(tau, bound); tau_hi = widen(tau); }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accs[1][r] = tau_max;  // "previous subtile" of the first one, again
+        }
+    }
+
     {   // Two stage buffers, one block barrier per stage.
         if (T > 0) SCMIAC_STAGE(stage_row(0), 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -598,25 +689,7 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
             SCMIAC_LOAD_NORMS(0, 0);
             SCMIAC_LOAD_GROUP(0, 0, 0);
             SCMIAC_LOAD_GROUP(0, 1, 1);
-            // the subtiles of a stage, written out: their numbers must be compile-time constants
-            // (ring slots, LDS offsets), whatever the optimizer thinks of unrolling a loop this big
-            static_assert(NSUB == 2 || NSUB == 4 || NSUB == 8 || NSUB == 10, "stage of 64, 128, 256 or 320 rows");
-            SCMIAC_SUBTILE(0, 1, 0);
-            SCMIAC_SUBTILE(1, 0, 1);
-            if constexpr (NSUB > 2) {
-                SCMIAC_SUBTILE(0, 1, 2);
-                SCMIAC_SUBTILE(1, 0, 3);
-            }
-            if constexpr (NSUB > 4) {
-                SCMIAC_SUBTILE(0, 1, 4);
-                SCMIAC_SUBTILE(1, 0, 5);
-                SCMIAC_SUBTILE(0, 1, 6);
-                SCMIAC_SUBTILE(1, 0, 7);
-            }
-            if constexpr (NSUB > 8) {
-                SCMIAC_SUBTILE(0, 1, 8);
-                SCMIAC_SUBTILE(1, 0, 9);
-            }
+            SCMIAC_STAGE_SUBTILES(SCMIAC_TEST_PREV);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA loads have landed
             if (do_sync) __syncthreads();
         }
@@ -639,143 +712,7 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
 }
 
 #undef SCMIAC_TEST_PREV
-
-// --------------------------------------------------------------------------------
-// home_seed: a threshold for every query before the search starts.  Block b streams only the
-// home stages of query block b (same MFMA stage loop, no selection at all): every lane keeps
-// the running minimum of each of its 16 accumulator registers, separately for even and odd
-// subtiles, so a query ends up with 64 minima over 64 DISJOINT sets of home rows.  The kt-th
-// smallest of them has at least kt rows scoring no more than itself: an upper bound of the
-// query's kt-th smallest score over all references, typically the ~50th smallest score of the
-// home rows.  The search then starts from it instead of from "everything passes", which
-// removes the cold start (hundreds of candidates and half a dozen merges per query).
-// --------------------------------------------------------------------------------
-// (not inlined: inlined into the kernel below, whose stage loop carries scheduling directives,
-// this network sent the compiler into a pass that did not finish within an hour)
-__device__ __attribute__((noinline)) unsigned wave_sort_u32(unsigned v, int lane) {
-#pragma unroll
-    for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            const unsigned o = (unsigned)__shfl_xor((int)v, j);
-            const bool up = (lane & k) == 0, low = (lane & j) == 0;
-            v = (up == low) ? (v < o ? v : o) : (v < o ? o : v);
-        }
-    }
-    return v;
-}
-
-#define SCMIAC_TEST_PREV(PRV_)                                                                      \
-    do {                                                                                            \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) gmin[PRV_][r] = fminf(gmin[PRV_][r], accs[PRV_][r]); \
-    } while (0)
-
-template <int D2, int NW_, int RT_>
-__global__ __launch_bounds__(NW_ * 64, (NW_ >= 8 ? NW_ / 4 : 2)) void home_seed_kernel(
-    const float* __restrict__ Qp, const float* __restrict__ Rp, const float* __restrict__ rnorm, long long n,
-    const int* __restrict__ home, int kt, int combine, float* __restrict__ tau0) {
-    using C = FusedCfg<D2, NW_, RT_, 32, true>;
-    constexpr int D2P = C::D2P, ROWF = C::ROWF, LS = C::LS, RT = C::RT, NW = C::NW;
-    constexpr int NSUB = RT / 32, NB = C::NB;
-    constexpr int STAGE_BYTES = RT * LS * 4;
-    constexpr int NCHUNK = STAGE_BYTES / 1024;
-    constexpr int LD_ITERS = (NCHUNK + NW - 1) / NW;
-    constexpr int NORM_CHUNKS = RT / 64;
-    static_assert(STAGE_BYTES % 1024 == 0 && RT % 64 == 0 && NORM_CHUNKS <= NW, "stage geometry");
-    // (the launcher sizes the dynamic LDS to hold every wave's 32 x 64 minima afterwards as well)
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* tile = reinterpret_cast<float*>(smem);  // [NB][RT*LS]
-    float* tnorm = tile + NB * RT * LS;            // [NB][RT]
-    const unsigned tile_lds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)tile;
-    const unsigned tnorm_lds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)tnorm;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j = lane & 31, hh = lane >> 5;
-    const int qb = blockIdx.x;
-    const long long q0 = (long long)qb * C::QPB + wave * 32;
-    const int H0 = home[2 * qb], T = home[2 * qb + 1];
-    const float big = __uint_as_float(TAU_MAX_BITS);
-
-    float qf[D2P];
-    {
-        const float4* qp4 = reinterpret_cast<const float4*>(Qp + (q0 + j) * ROWF + hh * D2P);
-#pragma unroll
-        for (int c = 0; c < D2P / 4; ++c) {
-            float4 v = qp4[c];
-            qf[4 * c + 0] = v.x; qf[4 * c + 1] = v.y; qf[4 * c + 2] = v.z; qf[4 * c + 3] = v.w;
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < D2P; ++c) asm volatile("" : "+v"(qf[c]));
-
-    constexpr int NGRP = D2P / 4;
-    static_assert(NGRP >= 2, "two groups of lookahead");
-    f32x16 accs[2];
-    float fr[3][4];
-    unsigned ref0s[2] = {0u, 0u};
-    float gmin[2][16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { accs[1][r] = big; gmin[0][r] = big; gmin[1][r] = big; }
-
-    if (T > 0) SCMIAC_STAGE((long long)H0 * RT, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int t = 0; t < T; ++t) {
-        if (t + 1 < T) SCMIAC_STAGE((long long)(H0 + t + 1) * RT, (t + 1) & 1);
-        const float* tb = tile + (t & 1) * RT * LS;
-        const float* nb = tnorm + (t & 1) * RT;
-        const long long cur_row0 = (long long)(H0 + t) * RT;
-        SCMIAC_LOAD_NORMS(0, 0);
-        SCMIAC_LOAD_GROUP(0, 0, 0);
-        SCMIAC_LOAD_GROUP(0, 1, 1);
-        static_assert(NSUB == 2 || NSUB == 4 || NSUB == 8 || NSUB == 10, "stage of 64, 128, 256 or 320 rows");
-        SCMIAC_SUBTILE(0, 1, 0);
-        SCMIAC_SUBTILE(1, 0, 1);
-        if constexpr (NSUB > 2) {
-            SCMIAC_SUBTILE(0, 1, 2);
-            SCMIAC_SUBTILE(1, 0, 3);
-        }
-        if constexpr (NSUB > 4) {
-            SCMIAC_SUBTILE(0, 1, 4);
-            SCMIAC_SUBTILE(1, 0, 5);
-            SCMIAC_SUBTILE(0, 1, 6);
-            SCMIAC_SUBTILE(1, 0, 7);
-        }
-        if constexpr (NSUB > 8) {
-            SCMIAC_SUBTILE(0, 1, 8);
-            SCMIAC_SUBTILE(1, 0, 9);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-    (void)ref0s;
-    if (T > 0) SCMIAC_TEST_PREV(1);  // the last subtile
-    // every wave has passed the last barrier: the stage buffers are free.  This wave's slice:
-    // [query 0..31][64 minima]; lane (j, hh) holds minima hh*32 .. hh*32+31 of query j
-    float* mine = tile + wave * (32 * 64);
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mine[j * 64 + hh * 32 + s * 16 + r] = gmin[s][r];
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    float out = big;
-#pragma clang loop unroll(disable)
-    for (int q = 0; q < 32; ++q) {
-        const unsigned v = wave_sort_u32(f2ord(mine[q * 64 + lane]), lane);
-        const float kth = ord2f((unsigned)__shfl((int)v, kt - 1));
-        if (j == q) out = kth;
-    }
-    if (hh == 0 && q0 + j < n) {
-        // the search compares keys (scores with four replaced mantissa bits): widen like tau_hi
-        float t = out < big ? out + fabsf(out) * 3.814697265625e-06f + 1e-30f : big;
-        if (combine) t = fminf(t, tau0[q0 + j]);
-        tau0[q0 + j] = t;
-    }
-}
-#undef SCMIAC_TEST_PREV
+#undef SCMIAC_SEED_PREV
 
 // --------------------------------------------------------------------------------
 // refine: one wave per query.  Exact D for the shortlisted references (oracle
@@ -1026,8 +963,8 @@ int knn_pick_d2(int d) {
 template <int D2, int NW, int RT, int PC, bool GP, bool DIAG>
 static hipError_t launch_fused_t(const float* Qp, const float* Rp, const float* rnorm, u64* lists, uint2* pend_g,
                                  long long n, long long n_pad, int nqb, int S, long long chunk_rows,
-                                 const FusedTail& tail, int kt, int ablate, const int* home, const float* tau0,
-                                 float* tau_out, u64* diag, hipStream_t stream) {
+                                 const FusedTail& tail, int kt, int ablate, const int* home, int seed_stages,
+                                 const float* tau0, float* tau_out, u64* diag, hipStream_t stream) {
     using C = FusedCfg<D2, NW, RT, PC, GP>;
     size_t lds = C::lds_bytes();
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_knn_kernel<D2, NW, RT, PC, GP, DIAG>),
@@ -1035,7 +972,7 @@ static hipError_t launch_fused_t(const float* Qp, const float* Rp, const float* 
     if (e != hipSuccess) return e;
     dim3 grid((unsigned)(tail.block0 + (nqb - tail.qb0) * tail.St)), block(NW * 64);
     hipLaunchKernelGGL((fused_knn_kernel<D2, NW, RT, PC, GP, DIAG>), grid, block, lds, stream, Qp, Rp, rnorm, lists, pend_g, n,
-                       n_pad, nqb, chunk_rows, tail, kt, ablate, home, tau0, tau_out, diag);
+                       n_pad, nqb, chunk_rows, tail, kt, ablate, home, seed_stages, tau0, tau_out, diag);
     return hipGetLastError();
 }
 
@@ -1135,13 +1072,14 @@ KnnGeometry knn_geometry(long long n, long long m, int d, int k, int splits) {
     fused_variant(g.D2, tn, &g.nw, &g.RT, &g.pcap, &g.gp);
     // locality partition: worth its passes over both sets once the stream is long enough to have
     // a candidate-dense start worth cutting; its kernels hold a block's rows and the pivots in LDS
-    g.cells = 0; g.cells_pad = 0; g.home_max = 0;
+    g.cells = 0; g.cells_pad = 0; g.home_max = 0; g.seed_stages = 0;
     if (!tn.no_locality && d <= 64 && m >= 16384 && n >= 2048) {
         long long c = m / 2048;
         c = c < 8 ? 8 : (c > 248 ? 248 : c);
         g.cells = (int)c;
         g.cells_pad = (g.cells + 7) & ~7;
         g.home_max = (8192 + g.RT - 1) / g.RT;  // a block streams at most this many home stages first
+        g.seed_stages = (3072 + g.RT - 1) / g.RT;  // ... and looks at this many of them for its thresholds
     }
     g.qpb = g.nw * 32;
     g.n_pad = ((n + g.qpb - 1) / g.qpb) * g.qpb;
@@ -1246,7 +1184,10 @@ static hipError_t launch_cells(const float* X, long long n, int d, const KnnGeom
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(assign_cells_kernel, dim3((unsigned)nblk), dim3(CELL_ROWS), lds, stream, X, n, d, pivT, pnorm, C,
                        Cpad, cell, blockhist);
-    hipLaunchKernelGGL(cell_offsets_kernel, dim3(1), dim3(256), 0, stream, blockhist, nblk, C, cell_start);
+    // (the totals pass through the tail of the start array's own allocation: C + 1 .. 2 C + 1)
+    int* col_total = cell_start + C + 1;
+    hipLaunchKernelGGL(cell_column_scan_kernel, dim3((unsigned)C), dim3(256), 0, stream, blockhist, nblk, C, col_total);
+    hipLaunchKernelGGL(cell_starts_kernel, dim3(1), dim3(64), 0, stream, col_total, C, cell_start);
     hipLaunchKernelGGL(cell_scatter_kernel, dim3((unsigned)nblk), dim3(CELL_ROWS), 0, stream, cell, n, C, blockhist,
                        cell_start, perm);
     return hipGetLastError();
@@ -1273,33 +1214,6 @@ static void knn_error_model(int d, const KnnGeometry& g, double* err_abs_coef, d
     *rel_keep = 1.0 - 2.0 * (double)(d + 4) * u;
 }
 
-template <int D2, int NW, int RT>
-static hipError_t launch_home_seed_t(const float* Qp, const float* Rp, const float* rnorm, long long n, int nqb,
-                                     const int* home, int kt, int combine, float* tau0, hipStream_t stream) {
-    using C = FusedCfg<D2, NW, RT, 32, true>;
-    const size_t minima = sizeof(float) * NW * 32 * 64;
-    const size_t lds = C::lds_bytes() > minima ? C::lds_bytes() : minima;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&home_seed_kernel<D2, NW, RT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((home_seed_kernel<D2, NW, RT>), dim3((unsigned)nqb), dim3(NW * 64), lds, stream, Qp, Rp, rnorm, n,
-                       home, kt, combine, tau0);
-    return hipGetLastError();
-}
-
-// thresholds from the home rows (tau0[q] = that bound, or the smaller of it and what tau0 holds)
-hipError_t launch_home_seed(const KnnGeometry& g, const float* Qp, const float* Rp, const float* rnorm, long long n,
-                            const int* home, int kt, int combine, float* tau0, hipStream_t stream) {
-#define SCMIAC_SEED_CASE(V_, NW_, RT_) \
-    if (g.D2 == V_ && g.nw == NW_ && g.RT == RT_) \
-        return launch_home_seed_t<V_, NW_, RT_>(Qp, Rp, rnorm, n, g.nqb, home, kt, combine, tau0, stream);
-    // the feature sizes the locality partition serves (d <= 64), in the library's own variants
-    SCMIAC_SEED_CASE(8, 12, 320) SCMIAC_SEED_CASE(15, 12, 320) SCMIAC_SEED_CASE(16, 12, 320)
-    SCMIAC_SEED_CASE(20, 12, 320) SCMIAC_SEED_CASE(25, 12, 320) SCMIAC_SEED_CASE(32, 12, 256)
-#undef SCMIAC_SEED_CASE
-    return hipErrorInvalidValue;
-}
-
 hipError_t launch_seed_tau(const float* Q, const int* perm_q, int d, long long n, const KnnGeometry& g, const int* idx,
                            const float* d2, int k, const unsigned* maxnorm_bits, float* tau0, hipStream_t stream) {
     double coef, keep;
@@ -1319,8 +1233,8 @@ hipError_t launch_fused(const KnnGeometry& g, const float* Qp, const float* Rp, 
     const int ablate = knn_get_tuning().ablate;
 #define SCMIAC_FUSED_CASE(V_, NW_, RT_, PC_, GP_)                                                  \
     if (g.D2 == V_ && g.nw == NW_ && g.RT == RT_ && g.pcap == PC_ && g.gp == GP_)                  \
-        return (diag || ablate) ? launch_fused_t<V_, NW_, RT_, PC_, (GP_ != 0), true>(Qp, Rp, rnorm, lists, pend_g, n, g.n_pad, g.nqb, g.S, g.chunk_rows, g.tail, kt, ablate, home, tau0, tau_out, diag, stream) \
-                    : launch_fused_t<V_, NW_, RT_, PC_, (GP_ != 0), false>(Qp, Rp, rnorm, lists, pend_g, n, g.n_pad, g.nqb, g.S, g.chunk_rows, g.tail, kt, 0, home, tau0, tau_out, diag, stream);
+        return (diag || ablate) ? launch_fused_t<V_, NW_, RT_, PC_, (GP_ != 0), true>(Qp, Rp, rnorm, lists, pend_g, n, g.n_pad, g.nqb, g.S, g.chunk_rows, g.tail, kt, ablate, home, g.seed_stages, tau0, tau_out, diag, stream) \
+                    : launch_fused_t<V_, NW_, RT_, PC_, (GP_ != 0), false>(Qp, Rp, rnorm, lists, pend_g, n, g.n_pad, g.nqb, g.S, g.chunk_rows, g.tail, kt, 0, home, g.seed_stages, tau0, tau_out, diag, stream);
     SCMIAC_FUSED_VARIANTS(SCMIAC_FUSED_CASE)
     return hipErrorInvalidValue;
 #undef SCMIAC_FUSED_CASE
