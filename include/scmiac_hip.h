@@ -188,10 +188,14 @@ SCMIAC_API int scmiac_anchor_filter(const int64_t *pairs, const int64_t *n_pairs
  *                  other feature sizes only is ignored for the rest.
  *   no_locality    1: stream the reference rows in the caller's order instead of regrouping
  *                  both sets by nearest pivot first (same result, A/B timing aid)
+ *   home_rows, seed_rows, cell_rows  > 0: override how many of its queries' home rows a
+ *                  block streams first (8192), how many of them the seed pass looks at
+ *                  (3072) and the reference rows per pivot cell aimed at (1024)
  * Thread-safe; affects searches planned after the call.
  */
 SCMIAC_API int scmiac_knn_set_tuning(int slots, int tail_min_rows, int no_tail, int ablate, int diag, int nw,
-                                     int rt, int pcap, int gp, int no_locality);
+                                     int rt, int pcap, int gp, int no_locality, int home_rows, int seed_rows,
+                                     int cell_rows);
 
 /*
  * Diagnostic aid (no counterpart in the reference).  When the `diag` knob of

@@ -43,7 +43,7 @@ _SIGNATURES = {
     "scmiac_knn_grid_plan": ([_i64, _i64, _i32, _i32, _i32, _c.POINTER(_i64)], _c.c_int),
     "scmiac_knn_kernel_name": ([_i64, _i64, _i32, _i32, _i32, _c.c_char_p, _sz], _c.c_int),
     "scmiac_knn_set_timing": ([_i32], _c.c_int),
-    "scmiac_knn_set_tuning": ([_i32] * 10, _c.c_int),
+    "scmiac_knn_set_tuning": ([_i32] * 13, _c.c_int),
     "scmiac_knn_fused_ms": ([_c.POINTER(_c.c_float), _c.POINTER(_c.c_int)], _c.c_int),
     "scmiac_closer_count_workspace_size": ([_i64, _i64, _i32, _c.POINTER(_sz)], _c.c_int),
     "scmiac_closer_count": ([_vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _sz, _vp], _c.c_int),
@@ -294,7 +294,8 @@ def knn_kernel_name(n, m, d, k, splits=0):
     return buf.value.decode()
 
 
-def set_tuning(*, slots=0, tail_min_rows=0, no_tail=False, ablate=0, diag=False, variant=None, no_locality=False):
+def set_tuning(*, slots=0, tail_min_rows=0, no_tail=False, ablate=0, diag=False, variant=None, no_locality=False,
+               home_rows=0, seed_rows=0, cell_rows=0):
     """Diagnostic / tuning knobs of the fused kernel's grid plan (``set_tuning()`` resets them).
     ``variant`` is ``"NWxRTxPCAPxGP"`` or a 4-tuple; an uncompiled one raises ``ValueError``."""
     nw = rt = pcap = gp = 0
@@ -304,7 +305,8 @@ def set_tuning(*, slots=0, tail_min_rows=0, no_tail=False, ablate=0, diag=False,
         pcap = parts[2] if len(parts) > 2 else 32
         gp = parts[3] if len(parts) > 3 else 0
     _check(load_library().scmiac_knn_set_tuning(int(slots), int(tail_min_rows), int(bool(no_tail)), int(ablate),
-                                                int(bool(diag)), nw, rt, pcap, gp, int(bool(no_locality))))
+                                                int(bool(diag)), nw, rt, pcap, gp, int(bool(no_locality)), int(home_rows),
+                                                int(seed_rows), int(cell_rows)))
 
 
 def set_timing(enabled: bool):

@@ -362,10 +362,10 @@ int scmiac_knn_set_timing(int enabled) {
 }
 
 int scmiac_knn_set_tuning(int slots, int tail_min_rows, int no_tail, int ablate, int diag, int nw, int rt, int pcap,
-                          int gp, int no_locality) {
+                          int gp, int no_locality, int home_rows, int seed_rows, int cell_rows) {
     FusedTuning t{};
     t.slots = slots; t.tail_min_rows = tail_min_rows; t.no_tail = no_tail; t.ablate = ablate; t.diag = diag;
-    t.no_locality = no_locality;
+    t.no_locality = no_locality; t.home_rows = home_rows; t.seed_rows = seed_rows; t.cell_rows = cell_rows;
     t.has_variant = (nw > 0 || rt > 0) ? 1 : 0;
     t.nw = nw; t.rt = rt; t.pcap = pcap; t.gp = gp;
     if (!knn_set_tuning(t))

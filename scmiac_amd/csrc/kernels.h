@@ -71,6 +71,9 @@ struct FusedTuning {
     int ablate;         // ablation bits of the diagnostic kernel instantiation
     int diag;           // 1: per-wave cycle counters into the workspace
     int no_locality;    // 1: stream the references in the caller's order (no pivot partition)
+    int home_rows;      // > 0: most home rows a query block streams first (default 8192)
+    int seed_rows;      // > 0: home rows the seed pass looks at (default 3072)
+    int cell_rows;      // > 0: reference rows per pivot cell aimed at (default 1024)
     int has_variant;    // 1: use (nw, rt, pcap, gp) where that combination is compiled
     int nw, rt, pcap, gp;
 };

@@ -995,7 +995,8 @@ bool knn_set_tuning(const FusedTuning& t) {
         for (int v : kD2Sizes) any = any || fused_variant_compiled(v, t.nw, t.rt, t.pcap, t.gp);
         if (!any) return false;
     }
-    if (t.slots < 0 || t.tail_min_rows < 0 || t.ablate < 0) return false;
+    if (t.slots < 0 || t.tail_min_rows < 0 || t.ablate < 0 || t.home_rows < 0 || t.seed_rows < 0 || t.cell_rows < 0)
+        return false;
     std::lock_guard<std::mutex> lock(g_plan_mu);
     g_tuning = t;
     return true;
@@ -1074,19 +1075,21 @@ KnnGeometry knn_geometry(long long n, long long m, int d, int k, int splits) {
     // a candidate-dense start worth cutting; its kernels hold a block's rows and the pivots in LDS
     g.cells = 0; g.cells_pad = 0; g.home_max = 0; g.seed_stages = 0;
     if (!tn.no_locality && d <= 64 && m >= 16384 && n >= 2048) {
-        long long c = m / 2048;
+        long long c = m / (tn.cell_rows > 0 ? tn.cell_rows : 1024);
         c = c < 8 ? 8 : (c > 248 ? 248 : c);
         g.cells = (int)c;
         g.cells_pad = (g.cells + 7) & ~7;
-        g.home_max = (8192 + g.RT - 1) / g.RT;  // a block streams at most this many home stages first
-        g.seed_stages = (3072 + g.RT - 1) / g.RT;  // ... and looks at this many of them for its thresholds
+        // a block streams at most this many home stages first ...
+        g.home_max = ((tn.home_rows > 0 ? tn.home_rows : 8192) + g.RT - 1) / g.RT;
+        // ... and looks at this many of them for its thresholds
+        g.seed_stages = ((tn.seed_rows > 0 ? tn.seed_rows : 3072) + g.RT - 1) / g.RT;
     }
     g.qpb = g.nw * 32;
     g.n_pad = ((n + g.qpb - 1) / g.qpb) * g.qpb;
     g.nqb = (int)(g.n_pad / g.qpb);
     const long long rows_rt = (m + g.RT - 1) / g.RT;  // reference rows in units of one LDS stage
     int slots = fused_concurrent_blocks(g);
-    long long min_chunk = 8192;  // shortest reference chunk considered
+    long long min_chunk = g.cells > 0 ? 2048 : 8192;  // shortest reference chunk considered
     // test aids: pretend the GPU runs fewer blocks at once / allow short chunks, so that
     // small problems exercise every region of the grid
     if (tn.slots > 0) slots = tn.slots;
@@ -1108,6 +1111,14 @@ KnnGeometry knn_geometry(long long n, long long m, int d, int k, int splits) {
         auto block_cycles = [&](double chunk) {
             if (chunk < 64.0) chunk = 64.0;
             const double sub = chunk / 32.0;                   // 32-row subtiles
+            if (g.cells > 0) {
+                // with the locality partition the thresholds start tight: what remains is the seed
+                // pass, the home rows' candidates and the closing merges -- a fixed price per
+                // block (fitted on MI355X: about 1.6 M cycles next to the seed pass) -- and a
+                // stream that runs at 84 % of the MFMA rate in chunk-sized pieces
+                const double mfma = g.D2 * 64.0 * (g.nw / 4);
+                return sub * mfma / 0.84 + g.seed_stages * (g.RT / 32.0) * mfma / 0.9 + 1.6e6;
+            }
             const double dense = 1024.0 * kt;                  // rows over which every subtile has candidates
             const double entries = chunk <= dense ? sub : dense / 32.0 * (1.0 + log(chunk / dense));
             const double merges = 64.0 + kt * log(chunk / 64.0);

@@ -1,0 +1,116 @@
+"""The locality partition of the search (rows regrouped by nearest pivot, every query block
+streaming its cell's reference rows first, thresholds seeded from those rows): the table must
+be the oracle's whatever the row order and however the grid is cut, and identical to the
+table of the plain caller-order stream."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle
+from scmiac_amd import _hip
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _clustered(seed, n, d, C, spread=1.0, unit=False):
+    rng = np.random.default_rng(seed)
+    centres = np.random.default_rng(500 + d).normal(scale=3.0, size=(C, d))
+    lab = rng.integers(0, C, n)
+    X = centres[lab] + spread * rng.normal(size=(n, d))
+    if unit:
+        X /= np.linalg.norm(X, axis=1, keepdims=True)
+    return X.astype(np.float32), lab
+
+
+@pytest.fixture
+def tuning():
+    try:
+        yield _hip.set_tuning
+    finally:
+        _hip.set_tuning()
+
+
+def _check(Q, R, k, **kw):
+    st = _hip.knn_search(_dev(Q), _dev(R), k, **kw)
+    torch.cuda.synchronize()
+    idx_o, d2_o = oracle.knn_dist2(Q, R, k)
+    np.testing.assert_array_equal(st.idx.cpu().numpy(), idx_o)
+    np.testing.assert_array_equal(st.dist2.cpu().numpy(), d2_o)
+    return st
+
+
+@pytest.mark.parametrize("order", ["random", "sorted by cluster", "sorted, queries reversed"])
+def test_any_row_order_gives_the_oracle_table(order, tuning):
+    Q, lq = _clustered(1, 6000, 50, 12)
+    R, lr = _clustered(2, 40000, 50, 12)
+    if order != "random":
+        R = R[np.argsort(lr, kind="stable")]
+        Q = Q[np.argsort(lq, kind="stable")]
+    if order.endswith("reversed"):
+        Q = Q[::-1].copy()
+    st = _check(Q, R, 30)
+    tuning(no_locality=True)
+    plain = _hip.knn_search(_dev(Q), _dev(R), 30)
+    assert torch.equal(plain.idx, st.idx) and torch.equal(plain.dist2, st.dist2)
+
+
+def test_chunks_and_tail_with_home_rows_inside_and_outside(tuning):
+    """A pretend 8-block GPU: query blocks searched in several reference chunks, most of which
+    do not contain the block's home rows (their thresholds still come from the seed pass)."""
+    Q, _ = _clustered(3, 5000, 30, 9, unit=True)
+    R, _ = _clustered(4, 50000, 30, 9, unit=True)
+    R[7000:7100] = R[11]      # 100 copies of one row: ties that outnumber a shortlist
+    Q[:10] = R[11]
+    tuning(slots=8, tail_min_rows=1024)
+    plan = _hip.knn_grid_plan(3300, 50000, 30, 31)   # 9 query blocks: 8 + a tail of 1, cut into chunks
+    assert plan["St"] > 1
+    _check(Q[:3300], R, 31)
+    _check(Q, R, 31)
+    _check(Q, R, 30, splits=5)
+    for knobs in (dict(cell_rows=300, home_rows=700, seed_rows=320), dict(cell_rows=6000, home_rows=20000, seed_rows=9000)):
+        tuning(slots=8, tail_min_rows=1024, **knobs)
+        _check(Q[:2500], R, 30)
+
+
+def test_merge_over_blocks_starts_from_the_running_distances():
+    """Reference blocks one after the other: later blocks start from thresholds derived from the
+    running k-th distance; duplicates across blocks tie at exactly that distance."""
+    Q, _ = _clustered(5, 4096, 64, 10, unit=True)
+    R, _ = _clustered(6, 60000, 64, 10, unit=True)
+    R[20000:20040] = R[3]     # block 2 repeats a row of block 1: equal distances, larger row numbers
+    R[45000] = R[3]
+    Q[:5] = R[3]
+    idx_o, d2_o = oracle.knn_dist2(Q, R, 30)
+    q, st = _dev(Q), None
+    cuts = (0, 18000, 41000, 60000)
+    for lo, hi in zip(cuts, cuts[1:]):
+        st = _hip.knn_search(q, _dev(R[lo:hi]), 30, col_offset=lo, state=st, exact_fallback=False)
+    n_unc = int(st.n_uncertified.item())
+    rows = st.uncertified_rows[:max(n_unc, 1)].clone()
+    n_rows = torch.tensor([n_unc], dtype=torch.int32, device="cuda")
+    for lo, hi in zip(cuts, cuts[1:]):
+        _hip.knn_exact_rows(q, _dev(R[lo:hi]), 30, rows, n_rows, st, col_offset=lo)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(st.idx.cpu().numpy(), idx_o)
+    np.testing.assert_array_equal(st.dist2.cpu().numpy(), d2_o)
+    # a block that holds nothing closer leaves the result alone and still certifies it
+    far = (R[:20000] + 50.0).astype(np.float32)
+    st2 = _hip.knn_search(q, _dev(far), 30, col_offset=60000, state=st, exact_fallback=False)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(st2.idx.cpu().numpy()[5:], idx_o[5:])
+
+
+def test_structureless_and_degenerate_inputs():
+    rng = np.random.default_rng(7)
+    Q = rng.normal(size=(3000, 20)).astype(np.float32)          # no clusters at all
+    R = rng.normal(size=(20000, 20)).astype(np.float32)
+    _check(Q, R, 30)
+    R2 = np.repeat(R[:200], 100, axis=0)                          # 200 distinct rows, 100 copies each
+    _check(Q[:2100], R2, 30)
+    Q3 = np.zeros((2500, 8), dtype=np.float32)                    # every query the same point
+    R3 = rng.normal(size=(17000, 8)).astype(np.float32)
+    _check(Q3, R3, 10)

@@ -417,6 +417,10 @@ def test_ring_search_unit_norm_d64_single_rank(tmp_path):
         b = anchor_search.find_neighbor_device(U, V, 30)
         for x, y in zip((a.G11, a.G12, a.G21, a.G22), (b.G11, b.G12, b.G21, b.G22)):
             assert torch.equal(x, y)
+        # the search sharded by rows of the first set (only G21 / G22 gathered) == the single-process one
+        pairs, raw = sharded.anchors_sharded(U, V, 30)
+        want = anchor_search.mnn_and_score(b, k_anchor=5, k_score=30)[0]
+        assert torch.equal(pairs, want.pairs[:want.n]) and torch.equal(raw, want.raw[:want.n]) and want.n > 0
         # closer-than-match counts through the sharded driver == the oracle's
         fx, fy = sharded.foscttm_sharded(U, _dev(_mixture(75, 700, 64, unit=True)))
         want_x, want_y = oracle.foscttm(U.cpu().numpy(), _mixture(75, 700, 64, unit=True))
