@@ -434,12 +434,21 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
     const int O1 = (H0 + HN < G0 + T) ? H0 + HN : G0 + T;
     const int oN = O1 > O0 ? O1 - O0 : 0;
     if (oN == 0) O0 = G0;
+    // Blocks that start together should also walk the rest of the reference rows together
+    // (each stage then comes out of the L2 for all but the first of them), although their seed
+    // passes and home stages differ in length: a block that has spent `shift` stage times on
+    // those enters the rest of its chunk `shift` stages in and wraps round at the end.
+    const int SN = (home != nullptr && T > 0) ? (HN < seed_stages ? HN : seed_stages) : 0;  // seed pass stages
+    const int rest = T - oN;
+    const int shift = rest > 0 ? (SN + oN) % rest : 0;
     auto stage_row = [=](int i) __attribute__((always_inline)) {  // first reference row of the i-th stage streamed
         int g;
         if (i < oN) {
             g = O0 + i;
         } else {
-            g = G0 + (i - oN);
+            int x = i - oN + shift;
+            if (x >= rest) x -= rest;
+            g = G0 + x;
             if (g >= O0) g += oN;
         }
         return (long long)g * RT;
@@ -633,12 +642,11 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
     // kt-th smallest score, typically near the 60th smallest score of the rows looked at.  The
     // search starts from it instead of from "everything passes", which removes the cold start
     // (hundreds of candidates and half a dozen merges per query).
-    if (home != nullptr && T > 0 && !(ablate & 32)) {
-        const int SN = HN < seed_stages ? HN : seed_stages;
+    if (SN > 0 && !(ablate & 32)) {
         float gmin[2][16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) { gmin[0][r] = tau_max; gmin[1][r] = tau_max; }
-        if (SN > 0) SCMIAC_STAGE((long long)H0 * RT, 0);
+        SCMIAC_STAGE((long long)H0 * RT, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         for (int t = 0; t < SN; ++t) {
@@ -653,7 +661,7 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
-        if (SN > 0) {
+        {
             SCMIAC_SEED_PREV(1);  // the last subtile
             float all[32];
 #pragma unroll
