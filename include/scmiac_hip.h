@@ -257,6 +257,16 @@ SCMIAC_API int scmiac_closer_count(const float *q, int64_t n, const float *r, in
                                    size_t workspace_bytes, void *stream);
 
 /*
+ * Row permutation of a partially pivoted LU factorisation, on the device: the `permute_l`
+ * part of scipy.linalg.lu as scikit-learn's randomized range finder uses it for
+ * TruncatedSVD, which scmiac/preprocessing/anchors.py:196-198 calls.  pivots [m] int32 are
+ * LAPACK's 1-based row interchanges (torch.linalg.lu_factor's second result), n the number
+ * of rows; perm [n] int64 receives the identity with the interchanges applied in order
+ * (perm[i] <-> perm[pivots[i]-1], i = 0..m-1), so that (P L)[perm] = L.
+ */
+SCMIAC_API int scmiac_lu_row_perm(const int32_t *pivots, int m, int64_t n, int64_t *perm, void *stream);
+
+/*
  * Symmetric NT-Xent loss between the two embeddings of a batch of anchor cells:
  * replaces NTXentLoss2.forward (scmiac/modeling/loss.py:96-133) and its autograd
  * backward, one launch each.  zi, zj: float32 [batch, d] row-major on the device,

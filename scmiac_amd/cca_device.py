@@ -74,12 +74,9 @@ def _lu_rows(y):
     lu, piv = torch.linalg.lu_factor(y)
     low = torch.tril(lu[:, :m], diagonal=-1)
     low[:m].diagonal().fill_(1.0)
-    piv = (piv.cpu().numpy().astype(np.int64) - 1)[:m]
-    perm = np.arange(n)
-    for i, p in enumerate(piv):  # row swaps in the order LAPACK applied them
-        perm[i], perm[p] = perm[p], perm[i]
+    perm = _hip.lu_row_perm(piv[:m], n)  # row swaps in the order LAPACK applied them, applied on the device
     out = torch.empty_like(low)
-    out[torch.from_numpy(perm).to(y.device)] = low
+    out[perm] = low
     return out
 
 

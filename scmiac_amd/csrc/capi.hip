@@ -205,11 +205,11 @@ int scmiac_knn_search(const float* q, int64_t n, const float* r, int64_t m, int 
     }
     if (slot >= 0) HIP_TRY(hipEventRecord(g_ev0[slot], stream), "event record");
     const bool diag = knn_get_tuning().diag != 0;  // diagnostic runs: per-wave cycle counters
-    HIP_TRY(launch_fused(g, w.qp, w.rp, w.rnorm, w.lists, w.pend, n, knn_threshold_rank(k), w.loc.home, tau0, w.tau_out,
+    HIP_TRY(launch_fused(g, w.qp, w.rp, w.rnorm, w.lists, w.pend, n, knn_threshold_rank(k, d), w.loc.home, tau0, w.tau_out,
                          diag ? w.diag : nullptr, stream),
             "fused distance + top-k");
     if (slot >= 0) HIP_TRY(hipEventRecord(g_ev1[slot], stream), "event record");
-    HIP_TRY(launch_refine(q, w.qp, w.rp, d, n, g, w.lists, k, knn_threshold_rank(k), col_offset, merge, w.maxnorm, w.tau_out,
+    HIP_TRY(launch_refine(q, w.qp, w.rp, d, n, g, w.lists, k, knn_threshold_rank(k, d), col_offset, merge, w.maxnorm, w.tau_out,
                           w.loc.perm_q, w.loc.perm_r, idx, dist2, dist, lower_bound, uncertified_rows, n_uncertified,
                           stream),
             "refine");
@@ -354,6 +354,15 @@ int scmiac_anchor_filter(const int64_t* pairs, const int64_t* n_pairs, int64_t n
     return SCMIAC_OK;
 }
 
+int scmiac_lu_row_perm(const int32_t* pivots, int m, int64_t n, int64_t* perm, void* stream_) {
+    if (m < 0 || n < 0 || m > n) return fail(SCMIAC_ERR_ARG, "need 0 <= m <= n (m=%d, n=%lld)", m, (long long)n);
+    if (n == 0) return SCMIAC_OK;
+    if (!perm || (m > 0 && !pivots)) return fail(SCMIAC_ERR_ARG, "NULL device pointer");
+    HIP_TRY(launch_lu_row_perm(pivots, m, n, reinterpret_cast<long long*>(perm), static_cast<hipStream_t>(stream_)),
+            "lu_row_perm");
+    return SCMIAC_OK;
+}
+
 int scmiac_knn_set_timing(int enabled) {
     std::lock_guard<std::mutex> lock(g_timing_mu);
     g_timing = enabled != 0;
@@ -432,13 +441,15 @@ int scmiac_closer_count(const float* q, int64_t n, const float* r, int64_t m, in
         return fail(SCMIAC_ERR_WORKSPACE, "internal: threshold region too small");
     HIP_TRY(hipMemsetAsync(w.maxnorm, 0, 256, stream), "memset maxnorm");
     HIP_TRY(hipMemsetAsync(status, 0, sizeof(int32_t), stream), "memset status");
-    HIP_TRY(launch_pack(q, n, d, g, -2.0f, w.qp, g.rowf, nullptr, g.n_pad, w.maxnorm, nullptr, stream), "pack queries");
-    HIP_TRY(launch_pack(r, m, d, g, 1.0f, w.rp, g.ls, w.rnorm, g.m_pad, w.maxnorm, nullptr, stream), "pack references");
+    // the locality partition serves the count as well: with both sets in cell order the references
+    // closer than a query's match sit in few stages, and every other subtile skips the counting
+    if (g.cells > 0) HIP_TRY(launch_locality(q, n, r, m, d, g, w.loc, stream), "locality partition");
+    HIP_TRY(launch_pack(q, n, d, g, -2.0f, w.qp, g.rowf, nullptr, g.n_pad, w.maxnorm, w.loc.perm_q, stream), "pack queries");
+    HIP_TRY(launch_pack(r, m, d, g, 1.0f, w.rp, g.ls, w.rnorm, g.m_pad, w.maxnorm, w.loc.perm_r, stream), "pack references");
     HIP_TRY(launch_closer_count(g, q, r, match, d, n, m, w.qp, w.rp, w.rnorm, w.maxnorm, lo, hi, dmatch, cnt, pend,
-                                status, stream),
+                                status, w.loc.perm_q, stream),
             "closer count");
-    HIP_TRY(hipMemcpyAsync(counts, cnt, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, stream),
-            "copy counts");
+    HIP_TRY(launch_scatter_counts(cnt, w.loc.perm_q, n, counts, stream), "counts to the caller's rows");
     return SCMIAC_OK;
 }
 

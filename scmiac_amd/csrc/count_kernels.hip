@@ -28,17 +28,18 @@ __global__ __launch_bounds__(256) void closer_thresholds_kernel(
     const float* __restrict__ Q, const float* __restrict__ R, const int* __restrict__ match, int d, long long n,
     long long n_pad, long long m, double err_abs_coef, double gamma, const unsigned* __restrict__ maxnorm_bits,
     float* __restrict__ lo, float* __restrict__ hi, float* __restrict__ dmatch, unsigned* __restrict__ counts,
-    int* __restrict__ status) {
-    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int* __restrict__ status, const int* __restrict__ perm_q /* packed position -> caller's row, or NULL */) {
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // position in the packed order
     if (q >= n_pad) return;
     counts[q] = 0u;
     float lf = -__builtin_inff(), hf = -__builtin_inff(), D = 0.0f;
     if (q < n) {
-        const long long mi = match ? (long long)match[q] : q;
+        const long long qo = perm_q ? (long long)perm_q[q] : q;
+        const long long mi = match ? (long long)match[qo] : qo;
         if (mi < 0 || mi >= m) {
             *status = 1;  // the row keeps count 0
         } else {
-            const float* qrow = Q + q * d;
+            const float* qrow = Q + qo * d;
             D = exact_dist2(qrow, R + mi * d, d);
             double qn = 0.0;
             for (int i = 0; i < d; ++i) qn += (double)qrow[i] * (double)qrow[i];
@@ -256,6 +257,20 @@ hipError_t launch_count_t(const KnnGeometry& g, const float* Qp, const float* Rp
 
 }  // namespace
 
+// counts of the packed order back to the caller's rows
+__global__ void scatter_counts_kernel(const unsigned* __restrict__ packed, const int* __restrict__ perm_q, long long n,
+                                      unsigned* __restrict__ out) {
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n) out[perm_q ? perm_q[q] : q] = packed[q];
+}
+
+hipError_t launch_scatter_counts(const unsigned* packed, const int* perm_q, long long n, unsigned* out,
+                                 hipStream_t stream) {
+    hipLaunchKernelGGL(scatter_counts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, packed, perm_q, n,
+                       out);
+    return hipGetLastError();
+}
+
 // bytes of the parked-reference buffers for a grid of this geometry
 size_t closer_count_pend_bytes(const KnnGeometry& g) {
     return (size_t)g.blocks * g.nw * 64 * kPendCap * sizeof(unsigned);
@@ -264,14 +279,14 @@ size_t closer_count_pend_bytes(const KnnGeometry& g) {
 hipError_t launch_closer_count(const KnnGeometry& g, const float* Q, const float* R, const int* match, int d,
                                long long n, long long m, const float* Qp, const float* Rp, const float* rnorm,
                                const unsigned* maxnorm_bits, float* lo, float* hi, float* dmatch, unsigned* counts,
-                               unsigned* pend, int* status, hipStream_t stream) {
+                               unsigned* pend, int* status, const int* perm_q, hipStream_t stream) {
     // the rounding-error model of the refine kernel's certificate, without the key term
     const double u = 5.9604644775390625e-08;  // 2^-24
     const double G = 2.0 * (double)(d + 2 * g.D2 + 4) * u;
     const double err_abs_coef = 2.0 * G;
     const double gamma = 2.0 * (double)(d + 4) * u;
     hipLaunchKernelGGL(closer_thresholds_kernel, dim3((unsigned)((g.n_pad + 255) / 256)), dim3(256), 0, stream, Q, R,
-                       match, d, n, g.n_pad, m, err_abs_coef, gamma, maxnorm_bits, lo, hi, dmatch, counts, status);
+                       match, d, n, g.n_pad, m, err_abs_coef, gamma, maxnorm_bits, lo, hi, dmatch, counts, status, perm_q);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
 #define SCMIAC_COUNT_CASE(V_, NW_, RT_) \

@@ -368,4 +368,28 @@ hipError_t launch_anchor_filter(const long long* pairs, const long long* n_pairs
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ LU row permutation
+// perm[0..n) <- identity, then LAPACK's row interchanges in order: swap(perm[i], perm[piv[i]-1])
+// for i = 0..m-1 (m is the number of columns of a tall block: a few dozen).  The swaps depend on
+// each other, so one thread applies them; the identity fill uses the whole block.
+__global__ __launch_bounds__(256) void lu_row_perm_kernel(const int* __restrict__ piv, int m, long long n,
+                                                          long long* __restrict__ perm) {
+    for (long long i = threadIdx.x; i < n; i += blockDim.x) perm[i] = i;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < m; ++i) {
+            long long p = (long long)piv[i] - 1;
+            if (p < 0 || p >= n) continue;  // not a LAPACK pivot: leave the row where it is
+            const long long a = perm[i], b = perm[p];
+            perm[i] = b;
+            perm[p] = a;
+        }
+    }
+}
+
+hipError_t launch_lu_row_perm(const int* piv, int m, long long n, long long* perm, hipStream_t stream) {
+    hipLaunchKernelGGL(lu_row_perm_kernel, dim3(1), dim3(256), 0, stream, piv, m, n, perm);
+    return hipGetLastError();
+}
+
 }  // namespace scmiac

@@ -83,7 +83,13 @@ bool knn_set_tuning(const FusedTuning& t);  // false: rejected (uncompiled varia
 int knn_pick_d2(int d);
 // rank of the shortlist entry whose key serves as the running threshold: the k wanted
 // neighbours plus a margin that the rounding-error certificate can absorb
-inline int knn_threshold_rank(int k) { return (k + 6 < 64) ? k + 6 : 64; }
+// (the certificate's error bound grows with the number of features while the gaps between
+// consecutive neighbour distances shrink: beyond 64 features the margin is 24 ranks instead of
+// 6, which turns thousands of uncertified rows per 200 000 into a handful)
+inline int knn_threshold_rank(int k, int d) {
+    const int margin = d > 64 ? 24 : 6;
+    return (k + margin < 64) ? k + margin : 64;
+}
 KnnGeometry knn_geometry(long long n, long long m, int d, int k, int splits);
 
 hipError_t launch_pack(const float* X, long long n, int d, const KnnGeometry& g, float scale, float* Xp,
@@ -122,12 +128,16 @@ hipError_t launch_anchor_filter(const long long* pairs, const long long* n_pairs
                                 long long* out_index, long long* counts, double* all_score, void* ws,
                                 hipStream_t stream);
 
+hipError_t launch_lu_row_perm(const int* piv, int m, long long n, long long* perm, hipStream_t stream);
+
 // count_kernels.hip: references closer than the true match, per query row
 size_t closer_count_pend_bytes(const KnnGeometry& g);
 hipError_t launch_closer_count(const KnnGeometry& g, const float* Q, const float* R, const int* match, int d,
                                long long n, long long m, const float* Qp, const float* Rp, const float* rnorm,
                                const unsigned* maxnorm_bits, float* lo, float* hi, float* dmatch, unsigned* counts,
-                               unsigned* pend, int* status, hipStream_t stream);
+                               unsigned* pend, int* status, const int* perm_q, hipStream_t stream);
+hipError_t launch_scatter_counts(const unsigned* packed, const int* perm_q, long long n, unsigned* out,
+                                 hipStream_t stream);
 
 // contrastive_kernels.hip
 int ntxent2_blocks(int B);

@@ -1115,7 +1115,7 @@ KnnGeometry knn_geometry(long long n, long long m, int d, int k, int splits) {
         S = splits;
         if (S > rows_rt) S = (int)(rows_rt > 0 ? rows_rt : 1);
     } else {
-        const double kt = (double)knn_threshold_rank(k);
+        const double kt = (double)knn_threshold_rank(k, d);
         auto block_cycles = [&](double chunk) {
             if (chunk < 64.0) chunk = 64.0;
             const double sub = chunk / 32.0;                   // 32-row subtiles
