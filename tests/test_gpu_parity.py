@@ -476,3 +476,25 @@ def test_knn_non_finite_rows_do_not_disturb_the_rest():
     rows = np.setdiff1d(np.arange(300), [5])
     np.testing.assert_array_equal(st.idx.cpu().numpy()[rows], keep[idx_o][rows])
     np.testing.assert_array_equal(st.dist2.cpu().numpy()[rows], d2_o[rows])
+
+
+def test_lu_row_permutation_on_the_device():
+    """``P @ L`` of a tall block's pivoted LU, the normaliser of the randomized range finder
+    behind ``cca`` (anchors.py:196-198 -> TruncatedSVD): permutation built by
+    ``scmiac_lu_row_perm`` on the device against scipy's."""
+    import scipy.linalg
+    from scmiac_amd.cca_device import _lu_rows
+
+    rng = np.random.default_rng(17)
+    for n, r in ((5000, 40), (64, 64), (300, 1)):
+        y = rng.normal(size=(n, r))
+        y[::7] *= 50.0                     # pivots far from the diagonal
+        got = _lu_rows(torch.from_numpy(y).cuda()).cpu().numpy()
+        want = scipy.linalg.lu(y, permute_l=True)[0]
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-12)
+    # pivots outside the block are refused before the launch, entries outside 1..n are left alone
+    piv = torch.tensor([3, 99, 2], dtype=torch.int32, device="cuda")
+    perm = _hip.lu_row_perm(piv, 4).cpu().numpy()
+    np.testing.assert_array_equal(perm, [2, 0, 1, 3])
+    with pytest.raises(ValueError):
+        _hip.lu_row_perm(torch.ones(5, dtype=torch.int32, device="cuda"), 3)

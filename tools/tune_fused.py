@@ -36,9 +36,11 @@ def main():
     ablate = int(os.environ.get("SCMIAC_FUSED_ABLATE", "0"))
     diag = os.environ.get("SCMIAC_FUSED_DIAG") == "1"
     no_tail = os.environ.get("SCMIAC_FUSED_NO_TAIL") == "1"
+    no_locality = os.environ.get("SCMIAC_NO_LOCALITY") == "1"
     for rnd in range(args.rounds + 1):
         for v in args.variants:
-            _hip.set_tuning(variant=None if v == "default" else v, ablate=ablate, diag=diag, no_tail=no_tail)
+            _hip.set_tuning(variant=None if v == "default" else v, ablate=ablate, diag=diag, no_tail=no_tail,
+                            no_locality=no_locality)
             _hip.set_timing(True)
             # ablated kernels leave poor shortlists: skip the direct-evaluation pass they would trigger
             ablated = ablate != 0
