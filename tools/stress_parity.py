@@ -3,6 +3,9 @@ the CPU oracle over random shapes (every feature-dimension bucket of the kernels
 row counts, duplicates, unit rows).  Exits non-zero on the first difference.
 
     python tools/stress_parity.py [--cases 60] [--seed 0] [--max-n 3000] [--max-m 40000]
+    python tools/stress_parity.py --locality [--cases 60]     shapes large enough for the locality partition
+                                  (n >= 2048, m >= 16384, d <= 64), random grid plans (pretend small GPUs, forced
+                                  chunk counts), random partition knobs, and searches merged over reference blocks
 """
 import argparse
 import sys
@@ -24,7 +27,10 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--max-n", type=int, default=3000)
     ap.add_argument("--max-m", type=int, default=40000)
+    ap.add_argument("--locality", action="store_true")
     a = ap.parse_args()
+    if a.locality:
+        a.max_n, a.max_m = max(a.max_n, 9000), max(a.max_m, 70000)
     rng = np.random.default_rng(a.seed)
     oracle.build()
     t0 = time.time()
@@ -33,6 +39,16 @@ def main():
                             161, 192, 200, 224, 225, 256]))
         n = int(rng.integers(1, a.max_n))
         m = int(rng.integers(1, a.max_m))
+        knobs, blocks = {}, 1
+        if a.locality:
+            d = int(rng.choice([2, 7, 16, 30, 31, 33, 40, 50, 51, 64]))
+            n, m = int(rng.integers(2048, a.max_n)), int(rng.integers(16384, a.max_m))
+            if rng.random() < 0.5:
+                knobs.update(slots=int(rng.choice([4, 8, 24])), tail_min_rows=int(rng.choice([512, 1024, 4096])))
+            if rng.random() < 0.5:
+                knobs.update(cell_rows=int(rng.choice([200, 1024, 5000])), home_rows=int(rng.choice([640, 8192, 30000])),
+                             seed_rows=int(rng.choice([320, 3072, 12000])))
+            blocks = int(rng.choice([1, 1, 2, 3]))
         k = int(min(m, rng.integers(1, 65)))
         nc = int(rng.integers(1, 12))
         centres = rng.normal(size=(nc, d)) * rng.uniform(0.1, 4)
@@ -49,14 +65,27 @@ def main():
             q *= 1e3
         qd, rd = torch.from_numpy(q).cuda(), torch.from_numpy(r).cuda()
         idx_o, d2_o = oracle.knn_dist2(q, r, k)
-        st = _hip.knn_search(qd, rd, k)
+        _hip.set_tuning(**knobs)
+        if blocks == 1:
+            st = _hip.knn_search(qd, rd, k, splits=int(rng.choice([0, 0, 3])) if a.locality else 0)
+        else:  # reference blocks merged one after the other, direct evaluation for what stays uncertified
+            cuts = np.linspace(0, m, blocks + 1).astype(int)
+            st = None
+            for lo, hi in zip(cuts, cuts[1:]):
+                st = _hip.knn_search(qd, rd[lo:hi], k, col_offset=int(lo), state=st, exact_fallback=False)
+            n_unc = int(st.n_uncertified.item())
+            rows = st.uncertified_rows[:max(n_unc, 1)].clone()
+            n_rows = torch.tensor([n_unc], dtype=torch.int32, device="cuda")
+            for lo, hi in zip(cuts, cuts[1:]):
+                _hip.knn_exact_rows(qd, rd[lo:hi], k, rows, n_rows, st, col_offset=int(lo))
         ok = np.array_equal(st.idx.cpu().numpy(), idx_o) and np.array_equal(st.dist2.cpu().numpy(), d2_o)
         match = rng.integers(0, m, n).astype(np.int32)
         cnt_o = oracle.closer_count(q, r, match)
         cnt = _hip.closer_count(qd, rd, match=torch.from_numpy(match).cuda()).cpu().numpy()
         ok2 = np.array_equal(cnt, cnt_o.astype(np.int64))
+        _hip.set_tuning()
         print(f"case {case:3d} n={n:5d} m={m:6d} d={d:3d} k={k:2d}  knn {'ok' if ok else 'DIFFERS'}  "
-              f"count {'ok' if ok2 else 'DIFFERS'}  uncertified={int(st.n_uncertified.item())}", flush=True)
+              f"count {'ok' if ok2 else 'DIFFERS'}  uncertified={int(st.n_uncertified.item())} blocks={blocks} {knobs}", flush=True)
         if not (ok and ok2):
             sys.exit(1)
     print(f"{a.cases} cases identical in {time.time() - t0:.0f} s")
