@@ -54,13 +54,15 @@ WORKLOADS = {
     # one GPU's share of the 4M x 2M, d=64 cosine atlas on 8 GPUs: its 500k query rows against all 2M
     # reference rows (what the ring delivers block by block); rows L2-normalised, so Euclidean = cosine order
     "c5shard": (500_000, 2_000_000, 64, 200, (5000, 5001, 5002)),
+    # the product's own shape: 30 canonical components, rows L2-normalised (anchors.py:877-878)
+    "cca30": (1_000_000, 1_000_000, 30, 100, (3000, 3001, 3002)),
     # a wide embedding (tuning aid for the d > 64 kernel variants)
     "wide": (200_000, 500_000, 100, 100, (7000, 7001, 7002)),
     "wide128": (200_000, 500_000, 128, 100, (7100, 7101, 7102)),
     "wide200": (200_000, 500_000, 200, 100, (7200, 7201, 7202)),
     "wide256": (200_000, 500_000, 256, 100, (7300, 7301, 7302)),
 }
-UNIT_NORM = {"c5shard"}
+UNIT_NORM = {"c5shard", "cca30"}
 
 
 def make_latents(name, n=None, m=None):
