@@ -84,6 +84,24 @@ def make_latents(name, n=None, m=None):
     return U, V, l1.astype(np.int32), l2.astype(np.int32), d
 
 
+class _stdout_to_stderr:
+    """Whatever native libraries print to stdout inside this block (RCCL announces its version
+    there when a communicator is created) goes to stderr instead: stdout carries rank 0's one
+    JSON line and nothing else."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)  # the C library's buffered stdout as well, while it still points at stderr
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 def spawn_ranks(n_ranks):
     """Start this script once per GPU under torch.distributed.run and return the launcher's
     exit status.  A child process, never an exec, and nothing here has touched the GPU yet."""
@@ -186,10 +204,12 @@ def main():
         backend = _hip
     if distributed:
         import torch.distributed as dist
-        if dry:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
+        with _stdout_to_stderr():
+            if dry:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=dev)
+            dist.barrier()  # the communicator exists from here on
 
     U, V, l1, l2, d = make_latents(args.workload, args.n, args.m)
     n, m, k = U.shape[0], V.shape[0], args.k
@@ -198,13 +218,27 @@ def main():
     q_dev = torch.from_numpy(U[lo:hi]).to(dev)
     r_dev = torch.from_numpy(V).to(dev)
 
+    # With several ranks every step ends with an all-gather of the shards' tables (every rank ends
+    # up with the whole table).  It is issued as soon as the search is queued and waited for one
+    # step later: the table travels over xGMI while the next one is searched.  All of it has
+    # arrived before the closing fence.
+    in_flight = []  # [(state, pending gather)] of the step before
+
+    def land():
+        while in_flight:
+            st_prev, pending = in_flight.pop()
+            st_prev.gathered = pending.wait()
+
     def step():
         st = sharded.knn_replicated(q_dev, r_dev, k, backend=backend)
         if distributed:
-            st.gathered = sharded.gather_rows(st.idx, n)  # every rank ends up with the whole table
+            pending = sharded.gather_rows_async(st.idx, n)
+            land()
+            in_flight.append((st, pending))
         return st
 
     def fence():
+        land()
         if distributed:
             dist.barrier()
         if not dry:
