@@ -51,6 +51,10 @@ WORKLOADS = {
     "c3": (1_000_000, 1_000_000, 50, 100, (2000, 2001, 2002)),
     "c2": (100_000, 100_000, 50, 50, (1000, 1001, 1002)),
     "small": (20_000, 20_000, 50, 20, (900, 901, 902)),
+    # imbalanced atlas: 200 cell types, 50 of them rare (0.1 % of the cells each), the other 150
+    # sharing 95 % with weights ~ 1/rank; 10 % of the ATAC labels replaced by another type -- the
+    # cell-type filter at work (the full_search object then reports what the rare types keep)
+    "c4": (100_000, 100_000, 50, 200, (3000, 3001, 3002)),
     # one GPU's share of the 4M x 2M, d=64 cosine atlas on 8 GPUs: its 500k query rows against all 2M
     # reference rows (what the ring delivers block by block); rows L2-normalised, so Euclidean = cosine order
     "c5shard": (500_000, 2_000_000, 64, 200, (5000, 5001, 5002)),
@@ -63,6 +67,7 @@ WORKLOADS = {
     "wide256": (200_000, 500_000, 256, 100, (7300, 7301, 7302)),
 }
 UNIT_NORM = {"c5shard", "cca30"}
+RARE_TYPES = 50  # of workload c4: labels 0..49
 
 
 def make_latents(name, n=None, m=None):
@@ -74,10 +79,18 @@ def make_latents(name, n=None, m=None):
     centres = rc.normal(scale=3.0, size=(C, d)).astype(np.float32)
     offset = rc.normal(scale=0.25, size=d).astype(np.float32)
     rr, ra = np.random.default_rng(s_r), np.random.default_rng(s_a)
-    l1 = rr.integers(0, C, n)
+    if name == "c4":
+        common = 1.0 / np.arange(1, C - RARE_TYPES + 1)
+        prior = np.r_[np.full(RARE_TYPES, 0.001), common / common.sum() * (1.0 - 0.001 * RARE_TYPES)]
+        l1, l2 = rr.choice(C, n, p=prior), ra.choice(C, m, p=prior)
+    else:
+        l1, l2 = rr.integers(0, C, n), ra.integers(0, C, m)
     U = centres[l1] + rr.standard_normal((n, d), dtype=np.float32)
-    l2 = ra.integers(0, C, m)
     V = centres[l2] + offset + ra.standard_normal((m, d), dtype=np.float32)
+    if name == "c4":  # the labels the filter sees on the ATAC side are predictions: 10 % of them wrong
+        flip = np.random.default_rng(3003).random(m) < 0.10
+        l2 = l2.copy()
+        l2[flip] = (l2[flip] + np.random.default_rng(3004).integers(1, C, int(flip.sum()))) % C
     if name in UNIT_NORM:
         U /= np.linalg.norm(U, axis=1, keepdims=True)
         V /= np.linalg.norm(V, axis=1, keepdims=True)
@@ -306,7 +319,7 @@ def main():
         out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(U[lo:hi], V, k, st, args.cpu_rows)
 
     if rank == 0 and not args.no_full and not distributed and not dry:
-        out["full_search"] = full_search(U, V, l1, l2, k, dev)
+        out["full_search"] = full_search(U, V, l1, l2, k, dev, rare=RARE_TYPES if args.workload == "c4" else 0)
 
     if distributed:
         dist.barrier()
@@ -366,8 +379,9 @@ def cpu_baseline_and_parity(Q, R, k, st, rows_arg):
     return cpu, parity
 
 
-def full_search(U, V, l1, l2, k, dev):
-    """One whole anchor search on the device: four tables, MNN, SNN score, label filter."""
+def full_search(U, V, l1, l2, k, dev, rare=0):
+    """One whole anchor search on the device: four tables, MNN, SNN score, label filter.
+    ``rare`` > 0: labels below it are the rare cell types; report what they keep."""
     u, v = torch.from_numpy(U).to(dev), torch.from_numpy(V).to(dev)
     c1, c2 = anchor_search.label_codes(l1, l2)
     c1, c2 = torch.from_numpy(c1).to(dev), torch.from_numpy(c2).to(dev)
@@ -380,9 +394,17 @@ def full_search(U, V, l1, l2, k, dev):
     kept = anchor_search.filter_anchors(scores, n_pairs, c1, c2)
     torch.cuda.synchronize(dev)
     t2 = time.perf_counter()
-    return {"tables_s": round(t1 - t0, 4), "mnn_score_filter_s": round(t2 - t1, 4),
-            "cells_per_s": round((U.shape[0] + V.shape[0]) / (t2 - t0), 1), "raw_anchors": scores.n,
-            "anchors_after_filter": int(len(kept.x1)), "uncertified_rows": list(tables.uncertified)}
+    res = {"tables_s": round(t1 - t0, 4), "mnn_score_filter_s": round(t2 - t1, 4),
+           "cells_per_s": round((U.shape[0] + V.shape[0]) / (t2 - t0), 1), "raw_anchors": scores.n,
+           "anchors_after_filter": int(len(kept.x1)), "uncertified_rows": list(tables.uncertified)}
+    if rare:
+        per_type = np.bincount(l1[kept.x1][l1[kept.x1] < rare], minlength=rare)
+        cells = np.bincount(l1[l1 < rare], minlength=rare)
+        res["rare_types"] = {"types": int(rare), "cells_per_type_median": float(np.median(cells)),
+                             "anchors_kept_total": int(per_type.sum()), "anchors_kept_per_type_min": int(per_type.min()),
+                             "anchors_kept_per_type_median": float(np.median(per_type)),
+                             "types_with_no_anchor": int((per_type == 0).sum())}
+    return res
 
 
 if __name__ == "__main__":
