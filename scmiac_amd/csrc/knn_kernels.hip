@@ -3,8 +3,12 @@
 // float32 direct-difference search.
 //
 // Pipeline of one scmiac_knn_search call (all on one stream, no host sync):
-//   pack_rows      Q, R  -> MFMA-friendly padded copies, |r|^2, max |r|^2
-//   fused_knn      for every query the 64 references with the smallest
+//   locality       (d <= 64, large sets) both sets regrouped by nearest pivot: permutations, and
+//                  per query block the stages of the reference image that hold its cell ("home")
+//   pack_rows      Q, R  -> MFMA-friendly padded copies (in cell order), |r|^2, max |r|^2
+//   seed_tau       (merge mode) thresholds to start from, out of the running k-th distances
+//   fused_knn      seed pass over the home rows (group minima -> a starting threshold per query),
+//                  then for every query the 64 references with the smallest
 //                  s(q,r) = |r|^2 - 2 q.r   (fp32 MFMA 32x32x2, refs staged in LDS,
 //                  running threshold in a register, per-lane candidate buffers in
 //                  global memory (L2) or LDS, wave-wide bitonic merges) -- the N x M
