@@ -92,6 +92,33 @@ inline int knn_threshold_rank(int k, int d) {
 }
 KnnGeometry knn_geometry(long long n, long long m, int d, int k, int splits);
 
+// arguments of one launch of the fused kernel that are not part of the geometry
+struct FusedLaunch {
+    const float* Qp;
+    const float* Rp;
+    const float* rnorm;
+    unsigned long long* lists;
+    void* pend_g;
+    long long n;
+    int kt;
+    int ablate;
+    const int* home;
+    const float* tau0;
+    float* tau_out;
+    unsigned long long* diag;
+    hipStream_t stream;
+};
+// one per translation unit of fused-kernel variants: hipErrorNotFound / 0 when the geometry's
+// variant is not among that unit's
+hipError_t launch_fused_tu0(const KnnGeometry& g, const FusedLaunch& a);
+hipError_t launch_fused_tu1(const KnnGeometry& g, const FusedLaunch& a);
+hipError_t launch_fused_tu2(const KnnGeometry& g, const FusedLaunch& a);
+hipError_t launch_fused_tu3(const KnnGeometry& g, const FusedLaunch& a);
+int fused_occupancy_tu0(const KnnGeometry& g);
+int fused_occupancy_tu1(const KnnGeometry& g);
+int fused_occupancy_tu2(const KnnGeometry& g);
+int fused_occupancy_tu3(const KnnGeometry& g);
+
 hipError_t launch_pack(const float* X, long long n, int d, const KnnGeometry& g, float scale, float* Xp,
                        int ld, float* norms, long long n_pad, unsigned* maxnorm_bits, const int* perm,
                        hipStream_t stream);

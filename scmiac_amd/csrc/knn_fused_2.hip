@@ -1,0 +1,7 @@
+// Group 2 of the fused k-NN kernel's variants (fused_variants.h).
+#include "fused_knn.h"
+#include "fused_variants.h"
+
+namespace scmiac {
+SCMIAC_DEFINE_FUSED_TU(2, SCMIAC_FUSED_VARIANTS_2)
+}  // namespace scmiac
