@@ -136,7 +136,15 @@ def test_matrix_free_cca_host_logic(golden, tag, monkeypatch):
     import torch
     from scmiac_amd import cca_device
 
+    def row_perm_on_the_host(pivots, n):
+        # stand-in for the device kernel: LAPACK's row interchanges applied in order
+        perm = np.arange(n, dtype=np.int64)
+        for i, p in enumerate(pivots.numpy() - 1):
+            perm[i], perm[p] = perm[p], perm[i]
+        return torch.from_numpy(perm)
+
     monkeypatch.setattr(cca_device, "_device", lambda: torch.device("cpu"))
+    monkeypatch.setattr(cca_device._hip, "lu_row_perm", row_perm_on_the_host)
     f = golden["f5_cca"]
     nc, cap, chunk, kf, scale2 = (int(v) for v in f[f"{tag}_args"])
     U, V, hdf = cca_device.cca_device(f[f"{tag}_X1"], f[f"{tag}_X2"], scale1=True, scale2=bool(scale2),
