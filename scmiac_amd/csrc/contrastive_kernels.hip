@@ -10,6 +10,14 @@
 // JT rows, each wave taking a quarter of every chunk (LDS reads of a row are broadcasts),
 // and the four partial results of an item meet in LDS.  A second, small kernel lets the
 // slices of an item meet.  S is recomputed in the backward pass instead of being stored.
+//
+// From a batch of kMfmaMinBatch items on, the first kernel of each pass is the MFMA one
+// (ntxent2_*_mfma_kernel): a wave owns 32 items as the B operand of v_mfma_f32_32x32x2f32 (lane
+// <-> item), the other side's rows are the A operand out of LDS, so a lane ends up with 16
+// entries of its own item's row (or column) of S and the log-sum-exp stays lane-local.  In the
+// backward pass the weights p of a 32 x 32 tile are, register for register, already laid out as
+// the B operand of the second product (gradient = sum_j p[j] zn[j]).  Both write the same
+// per-slice partial results as the FMA kernels; the finishing kernels are shared.
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
@@ -295,18 +303,254 @@ __global__ __launch_bounds__(128) void ntxent2_backward_finish_kernel(
         if (c < d) out[c] = (g[c] - zn[c] * proj) * inv;
 }
 
+
+// ------------------------------------------------------------------ MFMA path (large batches)
+typedef float nt_f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kMfmaMinBatch = 512;  // below this the FMA kernels' 64-item blocks fill the GPU better
+constexpr int kOwn = 128;           // items per block: 4 waves x 32
+
+template <int DP>
+struct NtM {
+    static constexpr int JT = 128;                               // rows of the other side per chunk
+    static constexpr int LS = DP + 1;                            // odd row stride: column reads hit distinct banks
+    static constexpr int kLdsFloats = JT * LS + JT;              // the rows + their lse values
+};
+
+// Both sides' rows, normalised and zero-padded to DP features: zn[side][row][DP].  Sixteen lanes
+// share a row (independent loads, one shuffle reduction), so a batch of thousands takes microseconds.
+template <int DP>
+__global__ __launch_bounds__(256) void ntxent2_normalise_kernel(const float* __restrict__ zi,
+                                                                const float* __restrict__ zj, int B, int d,
+                                                                float* __restrict__ zn) {
+    const int row = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;  // row of [2 B]
+    if (row >= 2 * B) return;  // (whole 16-lane groups leave together)
+    const float* src = (row < B ? zi : zj) + (size_t)(row < B ? row : row - B) * d;
+    float v[DP / 16];
+    float ss = 0.f;
+#pragma unroll
+    for (int u = 0; u < DP / 16; ++u) {
+        const int c = sub + 16 * u;
+        v[u] = (c < d) ? src[c] : 0.f;
+        ss = fmaf(v[u], v[u], ss);
+    }
+#pragma unroll
+    for (int off = 8; off; off >>= 1) ss += __shfl_xor(ss, off);
+    const float inv = 1.f / fmaxf(sqrtf(ss), kNormEps);
+#pragma unroll
+    for (int u = 0; u < DP / 16; ++u) zn[(size_t)row * DP + sub + 16 * u] = v[u] * inv;
+}
+
+// rows [c0, c0+JT) of one side (already normalised) into LDS with row stride LS; rows from j_hi on are zero
+template <int DP>
+__device__ inline void stage_chunk_m(const float* __restrict__ zn_other, int j_hi, int c0, float* lds) {
+    constexpr int JT = NtM<DP>::JT, LS = NtM<DP>::LS;
+    constexpr int V4 = DP / 4;  // float4 per row
+    for (int e = threadIdx.x; e < JT * V4; e += 256) {
+        const int r = e / V4, q = e - r * V4;
+        const int j = c0 + r;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j < j_hi) v = *reinterpret_cast<const float4*>(zn_other + (size_t)j * DP + 4 * q);
+        float* dst = lds + (size_t)r * LS + 4 * q;  // (odd row stride: scalar stores)
+        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    }
+}
+
+// B operand of the score product: features 2 s + h of item t's normalised row, s = 0 .. DP/2 - 1
+template <int DP>
+__device__ inline void load_own_operand(const float* __restrict__ zn_side, int t, int h, float (&q)[DP / 2]) {
+    const float2* src = reinterpret_cast<const float2*>(zn_side + (size_t)t * DP);
+#pragma unroll
+    for (int s = 0; s < DP / 2; ++s) {
+        const float2 v = src[s];
+        q[s] = h ? v.y : v.x;
+    }
+}
+
+// scores of the 32 rows at `rows` (LDS, stride LS) against the wave's 32 items: register r of lane
+// (n, h) = row (r & 3) + 8 (r >> 2) + 4 h  .  item n
+template <int DP>
+__device__ inline nt_f32x16 score_tile(const float* rows, const float (&q)[DP / 2], int n, int h) {
+    constexpr int LS = NtM<DP>::LS;
+    nt_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float* a = rows + (size_t)n * LS + h;
+#pragma unroll
+    for (int s = 0; s < DP / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * s], q[s], acc, 0, 0, 0);
+    return acc;
+}
+
+// running (max, sum exp) of a lane over the 16 scores of a tile; `valid` = rows of the tile that exist
+__device__ inline void lse_tile(const nt_f32x16& acc, float inv_t, int h, int valid, float& m, float& sum) {
+    float v[16];
+    float tm = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        v[r] = (row < valid) ? acc[r] * inv_t : -INFINITY;
+        tm = fmaxf(tm, v[r]);
+    }
+    if (tm > m) {  // (also the first tile with a valid row: m = -inf, sum = 0)
+        sum *= expf(m - tm);
+        m = tm;
+    }
+    if (m > -INFINITY) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += expf(v[r] - m);
+    }
+}
+
+// Forward, block (x, y, side): items 128 x .. 128 x + 127 of `side` (0: rows of S, own rows from
+// z_i; 1: columns of S, own rows from z_j) against the rows of slice y of the other side.
+// part[y][t] = (max, sum exp of row t; max, sum exp of column t): each side writes its half.
+template <int DP>
+__global__ __launch_bounds__(256) void ntxent2_forward_mfma_kernel(
+    const float* __restrict__ zn, int B, float inv_t, int slice_len, float4* __restrict__ part) {
+    constexpr int JT = NtM<DP>::JT, LS = NtM<DP>::LS;
+    extern __shared__ __align__(16) float lds[];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int n = lane & 31, h = lane >> 5;
+    const int side = blockIdx.z;
+    const int t = blockIdx.x * kOwn + w * 32 + n;
+    const int tc = (t < B) ? t : B - 1;
+    const int j_lo = blockIdx.y * slice_len;
+    const int j_hi = (j_lo + slice_len < B) ? j_lo + slice_len : B;
+    const float* zn_other = zn + (size_t)(1 - side) * B * DP;
+    float q[DP / 2];
+    load_own_operand<DP>(zn + (size_t)side * B * DP, tc, h, q);
+
+    float m = -INFINITY, sum = 0.f;
+    for (int c0 = j_lo; c0 < j_hi; c0 += JT) {
+        __syncthreads();
+        stage_chunk_m<DP>(zn_other, j_hi, c0, lds);
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < JT / 32; ++u) {
+            const int valid = j_hi - (c0 + 32 * u);  // wave-uniform
+            if (valid <= 0) break;
+            lse_tile(score_tile<DP>(lds + (size_t)(32 * u) * LS, q, n, h), inv_t, h, valid, m, sum);
+        }
+    }
+    // the two lane halves of an item saw different rows: let them meet
+    const float m2 = __shfl_xor(m, 32), sum2 = __shfl_xor(sum, 32);
+    if (h == 0 && t < B) {
+        const float M = fmaxf(m, m2);
+        float S = 0.f;
+        if (sum > 0.f) S += sum * expf(m - M);
+        if (sum2 > 0.f) S += sum2 * expf(m2 - M);
+        float2* out = reinterpret_cast<float2*>(part + (size_t)blockIdx.y * B + t);
+        out[side] = make_float2(M, S);
+    }
+}
+
+// gradient product of one tile: g[mb] += sum over the tile's 32 rows of p[row] * zn[row][32 mb + c].
+// The weights sit in the score tile's layout, which IS the B operand layout step by step: register
+// r of lane (n, h) belongs to row (r & 3) + 8 (r >> 2) + 4 h, i.e. k = h of MFMA step r.
+template <int DP>
+__device__ inline void grad_tile(const float* rows, const nt_f32x16& p, int n, int h, nt_f32x16 (&g)[DP / 32]) {
+    constexpr int LS = NtM<DP>::LS;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float* a = rows + (size_t)((r & 3) + 8 * (r >> 2) + 4 * h) * LS + n;  // A[feature n][k = h]
+#pragma unroll
+        for (int mb = 0; mb < DP / 32; ++mb)
+            g[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[32 * mb], p[r], g[mb], 0, 0, 0);
+    }
+}
+
+// Backward, block (x, y, side): gradient with respect to the normalised own rows of `side`, summed
+// over slice y of the other side: gpart[y][side][t][0..DP).  With s = S[t, j] (side 0) or S[j, t]
+// (side 1) the weight of the other side's row j is coef (exp(s - lse_own[t]) + exp(s - lse_other[j])
+// - 2 [j == t]), lse_own / lse_other = lse_row / lse_col for side 0 and the other way round for side 1.
+template <int DP>
+__global__ __launch_bounds__(256) void ntxent2_backward_mfma_kernel(
+    const float* __restrict__ zn, int B, float inv_t, int slice_len,
+    const float* __restrict__ lse_row, const float* __restrict__ lse_col, const float* __restrict__ grad_out,
+    float* __restrict__ gpart) {
+    constexpr int JT = NtM<DP>::JT, LS = NtM<DP>::LS;
+    extern __shared__ __align__(16) float lds[];
+    float* lse_chunk = lds + JT * LS;  // lse_other of the chunk's rows
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int n = lane & 31, h = lane >> 5;
+    const int side = blockIdx.z;
+    const int t = blockIdx.x * kOwn + w * 32 + n;
+    const int tc = (t < B) ? t : B - 1;
+    const int j_lo = blockIdx.y * slice_len;
+    const int j_hi = (j_lo + slice_len < B) ? j_lo + slice_len : B;
+    const float* zn_other = zn + (size_t)(1 - side) * B * DP;
+    const float* lse_own = side ? lse_col : lse_row;
+    const float* lse_other = side ? lse_row : lse_col;
+    float q[DP / 2];
+    load_own_operand<DP>(zn + (size_t)side * B * DP, tc, h, q);
+    nt_f32x16 g[DP / 32];
+#pragma unroll
+    for (int mb = 0; mb < DP / 32; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[mb][r] = 0.f;
+    const float l_t = lse_own[tc];
+    const float coef = 0.5f * grad_out[0] / (float)B * inv_t;
+
+    for (int c0 = j_lo; c0 < j_hi; c0 += JT) {
+        __syncthreads();
+        stage_chunk_m<DP>(zn_other, j_hi, c0, lds);
+        if (threadIdx.x < JT) {
+            const int j = c0 + threadIdx.x;
+            lse_chunk[threadIdx.x] = (j < j_hi) ? lse_other[j] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < JT / 32; ++u) {
+            if (j_hi - (c0 + 32 * u) <= 0) break;  // wave-uniform; rows beyond j_hi inside a tile are zero rows
+            const float* rows = lds + (size_t)(32 * u) * LS;
+            nt_f32x16 p = score_tile<DP>(rows, q, n, h);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ju = 32 * u + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float s = p[r] * inv_t;
+                const float same = (c0 + ju == t) ? 2.f : 0.f;
+                p[r] = coef * (expf(s - l_t) + expf(s - lse_chunk[ju]) - same);
+            }
+            grad_tile<DP>(rows, p, n, h, g);
+        }
+    }
+    // register r of lane (n, h), block mb: feature 32 mb + (r & 3) + 8 (r >> 2) + 4 h of item n
+    if (t < B) {
+        float* out = gpart + (((size_t)blockIdx.y * 2 + side) * B + t) * DP;
+#pragma unroll
+        for (int mb = 0; mb < DP / 32; ++mb)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                *reinterpret_cast<float4*>(out + 32 * mb + 8 * k + 4 * h) =
+                    make_float4(g[mb][4 * k], g[mb][4 * k + 1], g[mb][4 * k + 2], g[mb][4 * k + 3]);
+    }
+}
+
 // how the other side's rows are cut into slices: enough blocks to fill the GPU
 struct NtPlan {
     int blocks_x, n_slices, slice_len;
+    bool mfma;
 };
 inline NtPlan nt_plan(int B) {
     NtPlan p;
-    p.blocks_x = (B + kItems - 1) / kItems;
-    int s = (p.blocks_x >= 256) ? 1 : (256 + p.blocks_x - 1) / p.blocks_x;
+    p.mfma = B >= kMfmaMinBatch;
+    const int own = p.mfma ? kOwn : kItems;
+    p.blocks_x = (B + own - 1) / own;
+    // (the MFMA grid has a block per side as well: 256 blocks in x and y make 512 in all, two or
+    // three per compute unit, so that one block's staging and barriers hide behind another's products)
+    const int want = 256;
+    int s = (p.blocks_x >= want) ? 1 : (want + p.blocks_x - 1) / p.blocks_x;
     if (s > 16) s = 16;
     p.slice_len = (B + s - 1) / s;
     p.n_slices = (B + p.slice_len - 1) / p.slice_len;
     return p;
+}
+
+// floats of the per-slice partial results (forward: 4 per item and slice, backward: 2 DP); the MFMA
+// path keeps the normalised rows (2 B DP floats) behind them
+inline size_t nt_partial_floats(const NtPlan& p, int B, int dp) {
+    const size_t fwd = (size_t)p.n_slices * B * 4, bwd = (size_t)p.n_slices * 2 * B * dp;
+    return fwd > bwd ? fwd : bwd;
 }
 
 template <int DP>
@@ -315,8 +559,14 @@ hipError_t launch_fwd(const float* zi, const float* zj, int B, int d, float inv_
     const NtPlan p = nt_plan(B);
     size_t lds = (size_t)NtCfg<DP>::kLdsFloats * sizeof(float);
     float4* part = reinterpret_cast<float4*>(ws);
-    ntxent2_forward_kernel<DP><<<dim3(p.blocks_x, p.n_slices), kItems * kWaves, lds, stream>>>(
-        zi, zj, B, d, inv_t, p.slice_len, part);
+    if (p.mfma) {
+        float* zn = ws + nt_partial_floats(p, B, DP);  // behind the per-slice partial results
+        ntxent2_normalise_kernel<DP><<<(2 * B + 15) / 16, 256, 0, stream>>>(zi, zj, B, d, zn);
+        ntxent2_forward_mfma_kernel<DP><<<dim3(p.blocks_x, p.n_slices, 2), 256, NtM<DP>::kLdsFloats * sizeof(float), stream>>>(
+            zn, B, inv_t, p.slice_len, part);
+    } else
+        ntxent2_forward_kernel<DP><<<dim3(p.blocks_x, p.n_slices), kItems * kWaves, lds, stream>>>(
+            zi, zj, B, d, inv_t, p.slice_len, part);
     ntxent2_forward_finish_kernel<<<(B + 255) / 256, 256, 0, stream>>>(zi, zj, B, d, inv_t, p.n_slices, part,
                                                                       lse_row, lse_col, loss_parts);
     return hipGetLastError();
@@ -328,8 +578,14 @@ hipError_t launch_bwd(const float* zi, const float* zj, int B, int d, float inv_
                       hipStream_t stream) {
     const NtPlan p = nt_plan(B);
     size_t lds = (size_t)NtCfg<DP>::kLdsFloats * sizeof(float);
-    ntxent2_backward_kernel<DP><<<dim3(p.blocks_x, p.n_slices), kItems * kWaves, lds, stream>>>(
-        zi, zj, B, d, inv_t, p.slice_len, lse_row, lse_col, grad_out, ws);
+    if (p.mfma) {
+        float* zn = ws + nt_partial_floats(p, B, DP);
+        ntxent2_normalise_kernel<DP><<<(2 * B + 15) / 16, 256, 0, stream>>>(zi, zj, B, d, zn);
+        ntxent2_backward_mfma_kernel<DP><<<dim3(p.blocks_x, p.n_slices, 2), 256, NtM<DP>::kLdsFloats * sizeof(float), stream>>>(
+            zn, B, inv_t, p.slice_len, lse_row, lse_col, grad_out, ws);
+    } else
+        ntxent2_backward_kernel<DP><<<dim3(p.blocks_x, p.n_slices), kItems * kWaves, lds, stream>>>(
+            zi, zj, B, d, inv_t, p.slice_len, lse_row, lse_col, grad_out, ws);
     ntxent2_backward_finish_kernel<DP><<<(2 * B + 127) / 128, 128, 0, stream>>>(zi, zj, B, d, p.n_slices, ws, dzi,
                                                                               dzj);
     return hipGetLastError();
@@ -342,8 +598,7 @@ int ntxent2_blocks(int B) { return (B + 255) / 256; }
 size_t ntxent2_workspace_bytes(int B, int d) {
     const NtPlan p = nt_plan(B);
     const int dp = (d <= 32) ? 32 : 64;
-    size_t fwd = (size_t)p.n_slices * B * 4, bwd = (size_t)p.n_slices * 2 * B * dp;
-    return sizeof(float) * (fwd > bwd ? fwd : bwd);
+    return sizeof(float) * (nt_partial_floats(p, B, dp) + (p.mfma ? (size_t)2 * B * dp : 0));
 }
 
 hipError_t launch_ntxent2_forward(const float* zi, const float* zj, int B, int d, float temperature, float* lse_row,

@@ -33,7 +33,9 @@ def test_ntxent2_matches_reference_fixture(golden, tag):
 
 
 @pytest.mark.parametrize("B,d,T", [(1, 5, 0.5), (2, 1, 0.5), (63, 32, 0.2), (65, 33, 0.5), (129, 64, 0.07),
-                                   (1000, 30, 0.5), (4096, 16, 0.5)])
+                                   (1000, 30, 0.5), (4096, 16, 0.5),
+                                   # the MFMA kernels' range: partial chunks, partial tiles, both widths
+                                   (512, 30, 0.5), (513, 33, 0.2), (777, 50, 0.1), (2049, 64, 0.07)])
 def test_ntxent2_shapes_against_oracle(B, d, T):
     rng = np.random.default_rng(B * 131 + d)
     base = rng.normal(size=(B, d))
