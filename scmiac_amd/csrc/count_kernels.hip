@@ -160,20 +160,39 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
         }
         pcnt = 0u;
     };
-    // some score of the subtile lies below `hi`: count the ones below `lo` (a compare into a
-    // scalar mask and an add-with-carry per register) and park the references whose score
-    // falls in [lo, hi)
+    // Some score of the subtile may lie below `hi`.  t = score - lo (two registers per packed
+    // subtract; the sign of a float difference is exact): the sign bits are shifted into four short
+    // histories (one funnel shift per register, four independent chains) and counted with one
+    // population count; the smallest non-negative t (an unsigned minimum over the raw bits,
+    // negative floats sort last) tells whether any score lies in [lo, hi), since
+    // score < hi implies t <= fl(hi - lo).  The references in the band are parked as before.
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 lo2 = {lo, lo};
+    const unsigned band_bits = (hi > lo) ? __float_as_uint(hi - lo) : 0u;  // padding queries: lo = hi = -inf
     auto count_slow = [&](const f32x16& acc, unsigned ref0_wave) __attribute__((always_inline)) {
         f32x16 sc = acc;
         asm volatile("" : "+v"(sc));  // keeps this path's arithmetic behind the branch that guards it
-        u64 band = 0ull;
+        unsigned tbits[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const u64 ml = __ballot(sc[r] < lo), mh = __ballot(sc[r] < hi);
-            cnt += (sc[r] < lo) ? 1u : 0u;
-            band |= mh & ~ml;
+        for (int r = 0; r < 16; r += 2) {
+            const f32x2 t2 = (f32x2){sc[r], sc[r + 1]} - lo2;
+            tbits[r] = __float_as_uint(t2[0]);
+            tbits[r + 1] = __float_as_uint(t2[1]);
         }
-        if (__builtin_expect(band != 0ull, 0)) {
+        unsigned hist[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) hist[c] = __builtin_amdgcn_alignbit(hist[c], tbits[4 * c + r], 31);
+        }
+        cnt += (unsigned)__builtin_popcount(hist[0] | (hist[1] << 4) | (hist[2] << 8) | (hist[3] << 12));
+        auto umin3 = [](unsigned a, unsigned b, unsigned c) __attribute__((always_inline)) {
+            return min(min(a, b), c);
+        };
+        const unsigned u0 = umin3(tbits[0], tbits[1], tbits[2]), u1 = umin3(tbits[3], tbits[4], tbits[5]), u2 = umin3(tbits[6], tbits[7], tbits[8]);
+        const unsigned u3 = umin3(tbits[9], tbits[10], tbits[11]), u4 = umin3(tbits[12], tbits[13], tbits[14]);
+        const unsigned un = min(umin3(u0, u1, u2), umin3(u3, u4, tbits[15]));
+        if (__builtin_expect(__any(un <= band_bits), 0)) {
             if (__any(pcnt > (unsigned)(kPendCap - 16))) settle();
             const unsigned ref0 = ref0_wave + 4u * (unsigned)hh;
 #pragma unroll
