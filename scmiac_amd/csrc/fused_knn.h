@@ -149,7 +149,16 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
     long long r_begin, rows_here;
     long long list_row;  // row of the [.][64] shortlist array this wave's first query uses
     if ((int)blockIdx.x < tail.block0) {
-        split = blockIdx.x / tail.qb0; qb = blockIdx.x % tail.qb0;  // main region: qb0 query blocks
+        // Blocks are dealt round-robin over the 8 XCDs (block b runs on XCD b % 8), each with an L2
+        // of its own.  Within every aligned group of 256 block numbers, XCD x takes 32 CONSECUTIVE
+        // places of the (chunk, query block) order: neighbouring query blocks share cells, so their
+        // seed passes and home stages read the same reference rows and take about as long, and the
+        // 32 blocks then walk the rest of their chunk in step -- out of their XCD's L2.
+        int b = (int)blockIdx.x;
+#ifndef SCMIAC_NO_XCD_REMAP
+        if ((b | 255) < tail.block0) b = (b & ~255) | ((b & 7) << 5) | ((b & 255) >> 3);
+#endif
+        split = b / tail.qb0; qb = b % tail.qb0;  // main region: qb0 query blocks
         r_begin = (long long)split * chunk_rows;
         rows_here = chunk_rows;
         list_row = (long long)split * n_pad + (long long)qb * C::QPB + wave * 32;
