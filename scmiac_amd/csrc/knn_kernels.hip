@@ -326,8 +326,26 @@ __global__ __launch_bounds__(256) void refine_kernel(
         // that never came down from its ceiling means the list holds all there was
         float tau_s = tau_lists[lrow];
         if (tau_s >= __uint_as_float(TAU_MAX_BITS)) tau_s = __builtin_inff();
+        // Which entries are worth their 240-byte gather.  The list is ascending in the fused
+        // kernel's keys a (score within the certificate's error of the true |r|^2 - 2 q.r), so its
+        // first k entries have D <= (a_k + |q|^2 + E)(1 + gamma), and so has the running result's
+        // k-th entry, exactly.  An entry whose own lower bound (a + |q|^2 - E)(1 - gamma) lies
+        // above either cannot be among the k nearest: k others are strictly closer.
+        bool worth = ridx != 0xffffffffu;
+        {
+            const double E = err_abs_coef * (rmax2 + qn);
+            const unsigned kth_a = __builtin_amdgcn_readlane((unsigned)(e >> 32), k - 1);  // orderable bits, sentinel: +inf
+            double upper = ((double)ord2f(kth_a) + qn + E) * (2.0 - rel_keep);
+            const unsigned run_hi = __builtin_amdgcn_readlane((unsigned)(best >> 32), k - 1);
+            if (run_hi != 0xffffffffu) {
+                const double run_k = (double)__uint_as_float(run_hi);
+                upper = run_k < upper ? run_k : upper;
+            }
+            const double lower = (double)ord2f((unsigned)(e >> 32)) + qn - E;
+            if (lower > 0.0 && lower * rel_keep > upper) worth = false;
+        }
         u64 key = KEY_SENTINEL;
-        if (ridx != 0xffffffffu) {
+        if (worth) {
             float D = exact_dist2_packed(reinterpret_cast<const float4*>(Qp + qp * rowf),
                                          reinterpret_cast<const float4*>(Rp + (long long)ridx * ls), rowf / 4);
             const long long rrow = perm_r ? (long long)perm_r[ridx] : (long long)ridx;
