@@ -107,7 +107,9 @@ def mixture(seed, n, d):
 def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    oracle.build()
+    if rank == 0:
+        oracle.build()  # one rank compiles the checker if it is missing; the others wait
+    dist.barrier()
 
     # --- shard bounds and the gather, ragged and empty shards
     for n in (7, 1, 2 * world, 0):

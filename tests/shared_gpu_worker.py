@@ -86,7 +86,9 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
-    oracle.build()
+    if rank == 0:
+        oracle.build()  # one rank compiles the checker if it is missing; the others wait
+    dist.barrier()
 
     def up(a):
         return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
