@@ -278,7 +278,8 @@ SCMIAC_API int scmiac_lu_row_perm(const int32_t *pivots, int m, int64_t n, int64
  * backward: grad_out points at one float32 on the device (d loss); dzi, dzj receive
  * d loss / d zi, d loss / d zj.  The batch x batch similarity matrix is recomputed, not
  * stored.  Both take scmiac_ntxent2_workspace_size(batch, d) bytes of device scratch
- * (partial results of the up to 16 slices the other side's rows are cut into).
+ * (partial results of the up to 16 slices the other side's rows are cut into and, from
+ * 512 rows on, where the products run on MFMA, the normalised rows of both sides).
  */
 SCMIAC_API int scmiac_ntxent2_parts(int64_t batch);
 SCMIAC_API int scmiac_ntxent2_workspace_size(int64_t batch, int d, size_t *bytes);
