@@ -331,6 +331,10 @@ class SeuratIntegration:
         adata1, adata2 = self.adata_dict[i], self.adata_dict[j]
         min_sample = min(adata1.shape[0], adata2.shape[0])
         if i_sel is not None or j_sel is not None:
+            # The reference binds the selected cells to local names (anchors.py:819-822) that
+            # _prepare_matrix never sees (758-777 read self.adata_dict again), so its search runs on
+            # ALL cells and find_anchor then indexes the group's cell list with all-cell row numbers
+            # (1155-1156): an IndexError or silently wrong pairs.  There is no behaviour to mirror.
             raise NotImplementedError("per-group anchor search (key_match) is not provided")
         high_dim_feature = None
 
