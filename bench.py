@@ -11,7 +11,9 @@ One step = one whole table: pack both sets, fused fp32-MFMA distance + top-k,
 exact refine, direct-evaluation pass for uncertified rows.  With N > 1 ranks the
 query rows are sharded (references replicated) and the per-shard tables are
 all-gathered over RCCL inside the timed region; total work is fixed, so the
-scaling reported is "strong".
+scaling reported is "strong".  ``--ring`` shards the reference rows as well: every
+rank holds one block of them, the blocks travel round the ring of ranks and are
+merged into the running top-k (the 4M x 2M, d=64 cosine atlas: ``--workload c5 --ring``).
 
 Rank 0 prints one JSON line.  Next to the headline it carries
   roofline     -- the fused kernel against the fp32-MFMA peak: algorithmic flops
@@ -58,6 +60,8 @@ WORKLOADS = {
     # one GPU's share of the 4M x 2M, d=64 cosine atlas on 8 GPUs: its 500k query rows against all 2M
     # reference rows (what the ring delivers block by block); rows L2-normalised, so Euclidean = cosine order
     "c5shard": (500_000, 2_000_000, 64, 200, (5000, 5001, 5002)),
+    # the whole atlas (for --ring on 8 GPUs; one GPU needs about 7 s per table)
+    "c5": (4_000_000, 2_000_000, 64, 200, (5000, 5001, 5002)),
     # the product's own shape: 30 canonical components, rows L2-normalised (anchors.py:877-878)
     "cca30": (1_000_000, 1_000_000, 30, 100, (3000, 3001, 3002)),
     # a wide embedding (tuning aid for the d > 64 kernel variants)
@@ -66,7 +70,7 @@ WORKLOADS = {
     "wide200": (200_000, 500_000, 200, 100, (7200, 7201, 7202)),
     "wide256": (200_000, 500_000, 256, 100, (7300, 7301, 7302)),
 }
-UNIT_NORM = {"c5shard", "cca30"}
+UNIT_NORM = {"c5shard", "c5", "cca30"}
 RARE_TYPES = 50  # of workload c4: labels 0..49
 
 
@@ -186,6 +190,9 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU baseline sample (0 = auto: about 15 s of CPU work)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline / parity sample")
     ap.add_argument("--no-full", action="store_true", help="skip the full four-table anchor search timing")
+    ap.add_argument("--ring", action="store_true",
+                    help="shard the reference rows too and pass the blocks round the ring of ranks "
+                         "(sharded.knn_ring) instead of replicating them")
     ap.add_argument("--dry-launch", action="store_true",
                     help="rehearse the N-rank launch without GPUs: gloo on the CPU, the search replaced by a "
                          "stand-in; the JSON line is marked dry_launch and carries no throughput claim")
@@ -204,7 +211,12 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}: one rank per GPU is the contract")
     # SCMIAC_BENCH_FORCE_DIST=1 runs the multi-rank code path (process group, gather) with a
     # single rank: a rehearsal of the N > 1 launch on a one-GPU box
-    distributed = world > 1 or os.environ.get("SCMIAC_BENCH_FORCE_DIST") == "1"
+    distributed = world > 1 or args.ring or os.environ.get("SCMIAC_BENCH_FORCE_DIST") == "1"
+    if distributed and world == 1:  # a process group of one: the same code path, no launcher needed
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
     dry = args.dry_launch
     if dry:
         dev = torch.device("cpu")
@@ -229,7 +241,9 @@ def main():
     # query-row shard of this rank (contiguous blocks; references replicated)
     lo, hi = sharded.shard_bounds(n, world, rank)
     q_dev = torch.from_numpy(U[lo:hi]).to(dev)
-    r_dev = torch.from_numpy(V).to(dev)
+    # references: all of them on every rank, or (--ring) this rank's block of them
+    r_lo, r_hi = sharded.shard_bounds(m, world, rank) if args.ring else (0, m)
+    r_dev = torch.from_numpy(V[r_lo:r_hi]).to(dev)
 
     # With several ranks every step ends with an all-gather of the shards' tables (every rank ends
     # up with the whole table).  It is issued as soon as the search is queued and waited for one
@@ -243,7 +257,10 @@ def main():
             st_prev.gathered = pending.wait()
 
     def step():
-        st = sharded.knn_replicated(q_dev, r_dev, k, backend=backend)
+        if args.ring:
+            st = sharded.knn_ring(q_dev, r_dev, k, backend=backend)
+        else:
+            st = sharded.knn_replicated(q_dev, r_dev, k, backend=backend)
         if distributed:
             pending = sharded.gather_rows_async(st.idx, n)
             land()
@@ -279,13 +296,15 @@ def main():
     value = n / (elapsed / args.steps)
 
     n_local = hi - lo
-    flops = 2.0 * n_local * m * d
+    # one launch of the fused kernel: this rank's queries against all references, or (--ring)
+    # against one of the `world` blocks
+    flops = 2.0 * n_local * m * d / (world if args.ring else 1)
     if dry:
         roofline = None
     else:
         fused_avg_ms = fused_total_ms / max(fused_launches, 1)
         achieved = flops / (fused_avg_ms * 1e-3) / 1e12
-        kernel_name = _hip.knn_kernel_name(n_local, m, d, k)
+        kernel_name = _hip.knn_kernel_name(n_local, r_hi - r_lo, d, k)
         traffic, traffic_source = stored_traffic(args.workload if not (args.n or args.m) else None, n_local, kernel_name)
         roofline = {"bound": "mfma", "kernel": kernel_name, "achieved": round(achieved, 2),
                     "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
@@ -300,7 +319,8 @@ def main():
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: one cross-modal k-NN table, N={n} query x M={m} reference "
                                f"Gaussian-mixture latents, d={d}, k={k}",
-                   "sharding": "query rows sharded, references replicated, all-gather of the tables" if distributed else "single GPU",
+                   "sharding": ("query and reference rows sharded, reference blocks passed round the ring, all-gather of the tables" if args.ring
+                                else "query rows sharded, references replicated, all-gather of the tables" if distributed else "single GPU"),
                    "uncertified_rows_last_step": int(st.n_uncertified.item())},
         "roofline": roofline,
     }

@@ -42,6 +42,22 @@ def test_gpus_2_without_a_launcher_starts_two_ranks():
     assert out["config"]["table_checksum"] == int(idx.astype(np.int64).sum())
 
 
+def test_ring_mode_over_two_ranks_and_with_a_single_rank():
+    """``--ring``: reference rows sharded too, blocks passed round the ring; the gathered table is
+    still the unsharded oracle's.  With one rank the same code path runs in a process group of one."""
+    sys.path.insert(0, str(ROOT))
+    import bench
+    from oracle import oracle
+    U, V, *_ = bench.make_latents("small", 301, 401)
+    idx, _ = oracle.knn_dist2(U, V, 30)
+    for gpus in ("2", "1"):
+        args = ["--gpus", gpus, "--steps", "1", "--warmup", "1", "--workload", "small", "--n", "301", "--m", "401",
+                "--ring", "--dry-launch"]
+        out = _json_line(_run(args, {"SCMIAC_BENCH_DRY_BACKEND": "tests.gloo_worker:OracleBackend"}))
+        assert out["n_gpus"] == int(gpus) and "ring" in out["config"]["sharding"]
+        assert out["config"]["table_checksum"] == int(idx.astype(np.int64).sum())
+
+
 def test_gpus_3_no_compute_backend():
     out = _json_line(_run(["--gpus", "3", "--steps", "1", "--warmup", "0", "--workload", "small", "--n", "100",
                            "--m", "50", "--dry-launch"]))
