@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU session A of round 2: whole GPU test suite, single-rank rehearsal of the RCCL code path,
+# GPU session: whole GPU test suite, single-rank rehearsal of the RCCL code path,
 # C2 bench + kernel stats of the kernel as it stands.
 set -o pipefail
 R=$GRAFT_REPO_ROOT

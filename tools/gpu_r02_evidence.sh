@@ -1,5 +1,5 @@
 #!/bin/bash
-# One JSON line + rocprofv3 kernel stats for every number DESIGN.md quotes outside the bench.py
+# One JSON line + rocprofv3 kernel stats for every quoted number that lies outside the bench.py
 # workloads: CCA producer, loss / loaders, drop-in API at PBMC size, FOSCTTM count kernel.
 #   results: gpurun_out/profiles/r02_<name>.json and r02_<name>_kernel_stats.csv
 set -o pipefail

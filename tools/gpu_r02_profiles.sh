@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 evidence for the numbers quoted in DESIGN.md / README.md (round 2)
+# rocprofv3 evidence (bench line, kernel statistics, counter passes) for a list of bench.py workloads
 set -o pipefail
 cd $GRAFT_REPO_ROOT
 for spec in "$@"; do
