@@ -38,11 +38,16 @@ def knn_table(query, ref, k, *, want_dist=False, splits=0):
 
 
 def find_neighbor_device(cc1, cc2, k):
-    """anchors.py:525-566 on device tensors (float32, row-major)."""
+    """anchors.py:525-566 on device tensors (float32, row-major).  After
+    :func:`scmiac_amd.sharded.use_process_group` the query rows of every table are shared out over
+    the ranks of that group (every rank passes the same ``cc1`` / ``cc2`` and gets the whole tables)."""
     n1, n2 = cc1.shape[0], cc2.shape[0]
     kk = k + 1  # neighbor_graph is built with n_neighbors = k + 1, column 0 dropped
     if k < 1 or kk > _hip.KNN_MAX_K:
         raise ValueError(f"k={k} outside 1..{_hip.KNN_MAX_K - 1}")
+    from . import sharded  # (imports this module)
+    if sharded.active_group() is not None:
+        return sharded.find_neighbor_sharded(cc1, cc2, k, group=sharded.active_group().group)
     g11, _, s11 = knn_table(cc1, cc1, kk)
     g21, _, s21 = knn_table(cc2, cc1, k)
     g22, _, s22 = knn_table(cc2, cc2, kk)

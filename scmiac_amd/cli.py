@@ -41,6 +41,37 @@ def _read_h5ad(path):
     return anndata.read_h5ad(path)
 
 
+def _join_ranks():
+    """Started by ``torchrun --nproc-per-node N``: one rank per GPU, RCCL process group, and the
+    anchor search's k-NN tables shared out over the ranks.  Returns ``(rank, world)``; ``(0, 1)``
+    for a plain single-process start."""
+    import os
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 0, 1
+    import torch
+    import torch.distributed as dist
+
+    from . import sharded
+
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    sharded.use_process_group()
+    return dist.get_rank(), world
+
+
+def _leave_ranks():
+    import torch.distributed as dist
+
+    from . import sharded
+
+    sharded.use_process_group(enable=False)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def write_anchors(anchor_df, output_dir) -> Path:
     """``anchors.csv`` as the reference writes it: header x1,x2,score,x1_ct,x2_ct,is_same, no index."""
     output_dir = Path(output_dir)
@@ -58,6 +89,7 @@ def run_train(args: argparse.Namespace) -> int:
     adata_rna = _read_h5ad(args.rna_h5ad)
     adata_atac = _read_h5ad(args.atac_h5ad)
 
+    rank, world = _join_ranks()  # under torchrun: one rank per GPU, the searches shared out over them
     print("Generating MNN anchors...")
     anchor_df = find_anchors(
         adata_rna, adata_atac,
@@ -67,6 +99,10 @@ def run_train(args: argparse.Namespace) -> int:
         mode=args.mode,
         rna_celltype_key=args.rna_celltype_key, atac_celltype_key=args.atac_celltype_key,
     )
+    if world > 1:
+        _leave_ranks()
+        if rank != 0:  # every rank holds the same table: one of them writes it and goes on
+            return 0
     anchor_path = write_anchors(anchor_df, args.output_dir)
     print(f"MNN anchors saved to {anchor_path} ({len(anchor_df)} pairs)")
 

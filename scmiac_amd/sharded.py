@@ -26,6 +26,34 @@ from . import _hip
 from .anchor_search import NeighborTables
 
 
+class _ActiveGroup:
+    def __init__(self, group):
+        self.group = group  # None = the default group
+
+
+_active = None
+
+
+def use_process_group(group=None, enable=True):
+    """From now on the drop-in API (``find_neighbor``, ``SeuratIntegration.find_anchor``,
+    ``find_anchors``) shares the query rows of its k-NN tables out over the ranks of ``group``
+    (default: the whole initialised process group).  Opt-in on purpose: the searches become
+    collective calls, so EVERY rank of the group has to make them, with the same inputs; a
+    process group that exists for other reasons is left alone.  ``enable=False`` switches back."""
+    global _active
+    if not enable:
+        _active = None
+        return
+    if not dist.is_initialized():
+        raise RuntimeError("use_process_group needs an initialised torch.distributed process group")
+    _active = _ActiveGroup(group) if dist.get_world_size(group) > 1 else None
+
+
+def active_group():
+    """The group installed by :func:`use_process_group` (an object with a ``group`` member), or None."""
+    return _active
+
+
 def shard_bounds(n, world, rank):
     """Rows ``[lo, hi)`` of rank ``rank``: contiguous blocks of ``ceil(n / world)`` rows."""
     per = (n + world - 1) // world

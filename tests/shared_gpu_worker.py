@@ -130,6 +130,32 @@ def main():
     np.testing.assert_array_equal(raw.cpu().numpy(),
                                   np.asarray(oracle.snn_counts(want_pairs, G11, G12, G21, G22, 30), dtype=np.int32))
 
+    # --- the drop-in API with the searches shared out over the ranks (opt-in): numpy in, numpy /
+    # pandas out on every rank, equal to the single-process oracle
+    from scmiac_amd.preprocessing import anchors as drop_in
+
+    sharded.use_process_group()
+    note('drop-in API over the ranks')
+    for got, w in zip(drop_in.find_neighbor(U, V, k), want):
+        np.testing.assert_array_equal(got, w)
+
+    class _Ad:  # the handful of AnnData members the precomputed branch touches
+        def __init__(self, x):
+            self.obsm, self.shape = {"lat": x}, (x.shape[0], 1)
+
+    integ = drop_in.SeuratIntegration()
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        integ.find_anchor([_Ad(U.astype(np.float64)), _Ad(V.astype(np.float64))], key_anchor="lat", dim_red="precomputed",
+                          k_anchor=5, k_score=30)
+    odf, _, _ = oracle.pairwise_anchors(U, V, k_anchor=5, k_score=30)
+    got_df = integ.anchor[(0, 1)]
+    np.testing.assert_array_equal(got_df["x1"].values, odf["x1"].values)
+    np.testing.assert_array_equal(got_df["x2"].values, odf["x2"].values)
+    np.testing.assert_array_equal(got_df["score"].values, odf["score"].values)
+    sharded.use_process_group(enable=False)
+
     # --- closer-than-match counts, query rows sharded
     X = mixture(15, 5003, 30)
     Y = (X + np.random.default_rng(16).normal(size=X.shape)).astype(np.float32)

@@ -178,3 +178,15 @@ def test_host_tensors_are_rejected_before_any_launch(monkeypatch):
     with pytest.raises(ValueError, match="GPU device"):
         NTXentLoss2(0.5)(z, z)
     assert calls == []
+
+
+def test_process_group_wiring_is_opt_in():
+    """The drop-in API only turns collective after ``use_process_group``, which needs an
+    initialised process group; a plain process is untouched."""
+    from scmiac_amd import sharded
+
+    assert sharded.active_group() is None
+    with pytest.raises(RuntimeError):
+        sharded.use_process_group()
+    sharded.use_process_group(enable=False)
+    assert sharded.active_group() is None
