@@ -172,14 +172,18 @@ __global__ __launch_bounds__(256) void ntxent2_forward_finish_kernel(
         const float lr = M + logf(S), lc = Mc + logf(Sc);
         const float* a = zi + (size_t)t * d;
         const float* b = zj + (size_t)t * d;
+        // one pass over the two rows, eight features' loads in flight at a time (a loop that waits
+        // for every load before the next costs more than the rest of the kernel)
         float na = 0.f, nb = 0.f, ab = 0.f;
+#pragma unroll 8
         for (int c = 0; c < d; ++c) {
-            na = fmaf(a[c], a[c], na);
-            nb = fmaf(b[c], b[c], nb);
+            const float x = a[c], y = b[c];
+            na = fmaf(x, x, na);
+            nb = fmaf(y, y, nb);
+            ab = fmaf(x, y, ab);
         }
         const float ia = 1.f / fmaxf(sqrtf(na), kNormEps), ib = 1.f / fmaxf(sqrtf(nb), kNormEps);
-        for (int c = 0; c < d; ++c) ab = fmaf(a[c] * ia, b[c] * ib, ab);
-        const float diag = ab * inv_t;
+        const float diag = ab * ia * ib * inv_t;
         lse_row[t] = lr;
         lse_col[t] = lc;
         contrib = 0.5f * ((lr - diag) + (lc - diag));
@@ -444,6 +448,49 @@ __global__ __launch_bounds__(256) void ntxent2_forward_mfma_kernel(
     }
 }
 
+// Forward, second step of the MFMA path: as ntxent2_forward_finish_kernel, with the diagonal
+// S[t, t] taken from the normalised rows (compile-time width: sixteen-byte loads, all in flight
+// together, where the other kernel walks the raw rows feature by feature).
+template <int DP>
+__global__ __launch_bounds__(256) void ntxent2_forward_finish_zn_kernel(
+    const float* __restrict__ zn, int B, float inv_t, int n_slices, const float4* __restrict__ part,
+    float* __restrict__ lse_row, float* __restrict__ lse_col, float* __restrict__ loss_parts) {
+    __shared__ float red[4];
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    float contrib = 0.f;
+    if (t < B) {
+        float M = -INFINITY, Mc = -INFINITY;
+        for (int y = 0; y < n_slices; ++y) {
+            float4 p = part[(size_t)y * B + t];
+            if (p.y > 0.f) M = fmaxf(M, p.x);
+            if (p.w > 0.f) Mc = fmaxf(Mc, p.z);
+        }
+        float S = 0.f, Sc = 0.f;
+        for (int y = 0; y < n_slices; ++y) {
+            float4 p = part[(size_t)y * B + t];
+            if (p.y > 0.f) S += p.y * expf(p.x - M);
+            if (p.w > 0.f) Sc += p.w * expf(p.z - Mc);
+        }
+        const float lr = M + logf(S), lc = Mc + logf(Sc);
+        const float4* a = reinterpret_cast<const float4*>(zn + (size_t)t * DP);
+        const float4* b = reinterpret_cast<const float4*>(zn + ((size_t)B + t) * DP);
+        float ab = 0.f;
+#pragma unroll
+        for (int c = 0; c < DP / 4; ++c) {
+            const float4 x = a[c], y = b[c];
+            ab = fmaf(x.x, y.x, ab); ab = fmaf(x.y, y.y, ab); ab = fmaf(x.z, y.z, ab); ab = fmaf(x.w, y.w, ab);
+        }
+        const float diag = ab * inv_t;
+        lse_row[t] = lr;
+        lse_col[t] = lc;
+        contrib = 0.5f * ((lr - diag) + (lc - diag));
+    }
+    for (int off = 32; off; off >>= 1) contrib += __shfl_xor(contrib, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = contrib;
+    __syncthreads();
+    if (threadIdx.x == 0) loss_parts[blockIdx.x] = ((red[0] + red[1]) + (red[2] + red[3])) / (float)B;
+}
+
 // gradient product of one tile: g[mb] += sum over the tile's 32 rows of p[row] * zn[row][32 mb + c].
 // The weights sit in the score tile's layout, which IS the B operand layout step by step: register
 // r of lane (n, h) belongs to row (r & 3) + 8 (r >> 2) + 4 h, i.e. k = h of MFMA step r.
@@ -564,6 +611,9 @@ hipError_t launch_fwd(const float* zi, const float* zj, int B, int d, float inv_
         ntxent2_normalise_kernel<DP><<<(2 * B + 15) / 16, 256, 0, stream>>>(zi, zj, B, d, zn);
         ntxent2_forward_mfma_kernel<DP><<<dim3(p.blocks_x, p.n_slices, 2), 256, NtM<DP>::kLdsFloats * sizeof(float), stream>>>(
             zn, B, inv_t, p.slice_len, part);
+        ntxent2_forward_finish_zn_kernel<DP><<<(B + 255) / 256, 256, 0, stream>>>(zn, B, inv_t, p.n_slices, part, lse_row,
+                                                                                lse_col, loss_parts);
+        return hipGetLastError();
     } else
         ntxent2_forward_kernel<DP><<<dim3(p.blocks_x, p.n_slices), kItems * kWaves, lds, stream>>>(
             zi, zj, B, d, inv_t, p.slice_len, part);
