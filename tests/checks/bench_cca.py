@@ -1,7 +1,7 @@
 """Times the device CCA (matrix-free randomized SVD) against the CPU restatement that
 forms the dense cell x cell product like the reference (anchors.py:171-242).
 
-    python tools/bench_cca.py [--n1 10412 --n2 10412 --genes 3000 --components 30]
+    python tests/checks/bench_cca.py [--n1 10412 --n2 10412 --genes 3000 --components 30]
                               [--max-cc-cell 50000] [--no-cpu]
 
 Synthetic log-normalised counts; prints one JSON line."""
@@ -16,7 +16,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 
 
 def main():

@@ -3,7 +3,7 @@
 the 10x PBMC multiome set (10 412 x 10 412 cells, d=30, unit-norm rows), host arrays in,
 host arrays out, next to the CPU oracle on the same inputs.
 
-    python tools/bench_dropin.py [--n 10412] [--d 30]
+    python tests/checks/bench_dropin.py [--n 10412] [--d 30]
 """
 import argparse
 import sys
@@ -13,7 +13,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
-ROOT = Path(__file__).resolve().parents[1]
+ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT))
 from oracle import oracle  # noqa: E402  (checker / CPU baseline only)
 from scmiac_amd.preprocessing import anchors as A  # noqa: E402

@@ -2,7 +2,7 @@
 table is computed once, the oracle goes through the query rows in slices and the comparison is
 bit for bit (indices and squared distances).  Stops after --budget seconds and says how far it got.
 
-    python tools/full_parity.py [--workload c3] [--budget 1000] [--out gpurun_out/full_parity_c3.json]
+    python tests/checks/full_parity.py [--workload c3] [--budget 1000] [--out gpurun_out/full_parity_c3.json]
 """
 import argparse
 import json
@@ -13,7 +13,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
-ROOT = Path(__file__).resolve().parents[1]
+ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT))
 import bench  # noqa: E402
 from oracle import oracle  # noqa: E402  (checker)

@@ -2,8 +2,8 @@
 the CPU oracle over random shapes (every feature-dimension bucket of the kernels, ragged
 row counts, duplicates, unit rows).  Exits non-zero on the first difference.
 
-    python tools/stress_parity.py [--cases 60] [--seed 0] [--max-n 3000] [--max-m 40000]
-    python tools/stress_parity.py --locality [--cases 60]     shapes large enough for the locality partition
+    python tests/checks/stress_parity.py [--cases 60] [--seed 0] [--max-n 3000] [--max-m 40000]
+    python tests/checks/stress_parity.py --locality [--cases 60]     shapes large enough for the locality partition
                                   (n >= 2048, m >= 16384, d <= 64), random grid plans (pretend small GPUs, forced
                                   chunk counts), random partition knobs, and searches merged over reference blocks
 """
@@ -15,7 +15,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
-ROOT = Path(__file__).resolve().parents[1]
+ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT))
 from oracle import oracle  # noqa: E402  (checker)
 from scmiac_amd import _hip  # noqa: E402
