@@ -214,7 +214,10 @@ def main():
     distributed = world > 1 or args.ring or os.environ.get("SCMIAC_BENCH_FORCE_DIST") == "1"
     if distributed and world == 1:  # a process group of one: the same code path, no launcher needed
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29541")
+        if "MASTER_PORT" not in os.environ:
+            with socket.socket() as sock:  # any free port: nobody else joins this group
+                sock.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
     dry = args.dry_launch
