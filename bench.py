@@ -23,6 +23,7 @@ Rank 0 prints one JSON line.  Next to the headline it carries
                   timed on this box's host cores on a bounded sample of query rows;
                   the same rows double as the parity check of the GPU result
   full_search  -- all four tables + MNN + SNN score + label filter (one anchor search)
+  pruned_exact_search -- the same table with the opt-in pivot-pruning experiment (exact, not dense)
   pcie_inclusive -- one table with inputs starting and the result ending in host memory
 """
 from __future__ import annotations
@@ -342,6 +343,7 @@ def main():
         out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(U[lo:hi], V, k, st, args.cpu_rows)
 
     if rank == 0 and not args.no_full and not distributed and not dry:
+        out["pruned_exact_search"] = pruned_search(q_dev, r_dev, k, st)
         out["full_search"] = full_search(U, V, l1, l2, k, dev, rare=RARE_TYPES if args.workload == "c4" else 0)
 
     if distributed:
@@ -400,6 +402,32 @@ def cpu_baseline_and_parity(Q, R, k, st, rows_arg):
     parity = {"rows_checked": nrows, "rows_with_index_mismatch": bad_rows,
               "dist2_bit_identical": bool(np.array_equal(d2_g, d2_o))}
     return cpu, parity
+
+
+def pruned_search(q_dev, r_dev, k, dense):
+    """The same table with the pivot-pruning experiment switched on (tuning bit 64: farthest-point
+    pivots, and every block streams only the cells within reach of its queries).  Exact -- compared
+    here with the dense search's table bit for bit -- but not the dense contraction the headline
+    and the roofline are about: reported next to them, never as them.  None where the partition
+    does not apply."""
+    if q_dev.shape[1] > 64 or r_dev.shape[0] < 16384 or q_dev.shape[0] < 2048:
+        return None
+    try:
+        _hip.set_tuning(ablate=64)
+        _hip.knn_search(q_dev, r_dev, k)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            st = _hip.knn_search(q_dev, r_dev, k)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+    finally:
+        _hip.set_tuning()
+    return {"ms_per_table": round(dt * 1e3, 3), "cells_per_s": round(q_dev.shape[0] / dt, 1),
+            "identical_to_dense_search": bool(torch.equal(st.idx, dense.idx) and torch.equal(st.dist2, dense.dist2)),
+            "note": "experimental, opt-in (scmiac_knn_set_tuning): exact pruning by the partition's pivots; "
+                    "skips most of the dense contraction on clustered data, so it has no MFMA roofline"}
 
 
 def full_search(U, V, l1, l2, k, dev, rare=0):

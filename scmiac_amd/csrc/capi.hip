@@ -83,6 +83,13 @@ static KnnWs knn_carve(void* ws, long long n, long long m, int d, const KnnGeome
         w.loc.perm_q = reinterpret_cast<int*>(take(sizeof(int) * (size_t)n));
         w.loc.perm_r = reinterpret_cast<int*>(take(sizeof(int) * (size_t)m));
         w.loc.home = reinterpret_cast<int*>(take(sizeof(int) * 2 * (size_t)g.nqb));
+        if (g.prune) {  // pruning experiment: distances to the pivots, cell radii, per-block stage lists
+            w.loc.qpd = reinterpret_cast<float*>(take(sizeof(float) * (size_t)g.cells_pad * (size_t)n));
+            w.loc.crad = reinterpret_cast<unsigned*>(take(sizeof(unsigned) * (size_t)g.cells_pad));
+            size_t order_bytes = sizeof(unsigned short) * (size_t)g.blocks * (size_t)(g.chunk_rows / g.RT + 1);
+            if (order_bytes < sizeof(int) * (size_t)g.cells_pad) order_bytes = sizeof(int) * (size_t)g.cells_pad;
+            w.loc.order = reinterpret_cast<unsigned short*>(take(order_bytes));  // (its head first holds the pivots' rows)
+        }
     }
     w.diag = reinterpret_cast<unsigned long long*>(p + off);
     w.diag_offset = off;
@@ -182,6 +189,7 @@ int scmiac_knn_search(const float* q, int64_t n, const float* r, int64_t m, int 
 
     HIP_TRY(hipMemsetAsync(w.maxnorm, 0, 256, stream), "memset maxnorm");
     HIP_TRY(hipMemsetAsync(n_uncertified, 0, sizeof(int32_t), stream), "memset n_uncertified");
+    if (g.prune) HIP_TRY(hipMemsetAsync(w.loc.crad, 0, sizeof(unsigned) * (size_t)g.cells_pad, stream), "memset radii");
     if (g.cells > 0) HIP_TRY(launch_locality(q, n, r, m, d, g, w.loc, stream), "locality partition");
     HIP_TRY(launch_pack(q, n, d, g, -2.0f, w.qp, g.rowf, nullptr, g.n_pad, w.maxnorm, w.loc.perm_q, stream), "pack queries");
     HIP_TRY(launch_pack(r, m, d, g, 1.0f, w.rp, g.ls, w.rnorm, g.m_pad, w.maxnorm, w.loc.perm_r, stream), "pack references");
@@ -206,7 +214,7 @@ int scmiac_knn_search(const float* q, int64_t n, const float* r, int64_t m, int 
     if (slot >= 0) HIP_TRY(hipEventRecord(g_ev0[slot], stream), "event record");
     const bool diag = knn_get_tuning().diag != 0;  // diagnostic runs: per-wave cycle counters
     HIP_TRY(launch_fused(g, w.qp, w.rp, w.rnorm, w.lists, w.pend, n, knn_threshold_rank(k, d), w.loc.home, tau0, w.tau_out,
-                         diag ? w.diag : nullptr, stream),
+                         knn_prune_args(g, w.loc, w.maxnorm, n, d), diag ? w.diag : nullptr, stream),
             "fused distance + top-k");
     if (slot >= 0) HIP_TRY(hipEventRecord(g_ev1[slot], stream), "event record");
     HIP_TRY(launch_refine(q, w.qp, w.rp, d, n, g, w.lists, k, knn_threshold_rank(k, d), col_offset, merge, w.maxnorm, w.tau_out,

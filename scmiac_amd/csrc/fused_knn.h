@@ -114,6 +114,7 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
     int seed_stages,                  // most home stages the seed pass looks at
     const float* __restrict__ tau0,   // [n_pad] threshold to start from, or NULL
     float* __restrict__ tau_out,      // [shortlists] threshold each shortlist ended with
+    PruneArgs prune,                  // pruning experiment (diagnostic instantiation, tuning bit 64)
     u64* __restrict__ diag_out /* per wave 8 counters (DIAG_ instantiations only) */) {
     u64* const diag = DIAG_ ? diag_out : nullptr;  // compile-time NULL in the product kernel (may be NULL in the other too)
 #ifndef SCMIAC_ABL
@@ -192,9 +193,15 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
     const int SN = (home != nullptr && T > 0) ? (HN < seed_stages ? HN : seed_stages) : 0;  // seed pass stages
     const int rest = T - oN;
     const int shift = rest > 0 ? (SN + oN) % rest : 0;
-    auto stage_row = [=](int i) __attribute__((always_inline)) {  // first reference row of the i-th stage streamed
+    // (pruning experiment: after its seed pass a block may decide to stream only part of the rest
+    // of its chunk; the chunk-relative numbers of those stages then stand in `order`)
+    const unsigned short* order = nullptr;
+    int T_loop = T;
+    auto stage_row = [&](int i) __attribute__((always_inline)) {  // first reference row of the i-th stage streamed
         int g;
-        if (i < oN) {
+        if (DIAG_ && order != nullptr && i >= oN) {
+            g = G0 + (int)__hip_atomic_load(order + (i - oN), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (i < oN) {
             g = O0 + i;
         } else {
             int x = i - oN + shift;
@@ -434,12 +441,84 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
         }
     }
 
+    // Pruning experiment.  The partition's pivots give, for every cell c of the reference image,
+    // a lower bound of the distance from a query to anything in it: dist(q, p_c) - rho_c (rho_c
+    // the largest distance of the cell's rows to their pivot).  At least kt rows score no more
+    // than the query's threshold tau, i.e. lie within reach = sqrt(tau + |q|^2 + E) of it (E the
+    // score's error bound), and tau only falls from here on: a cell beyond the reach of all of
+    // the block's queries cannot hold one of their neighbours.  The block streams its home stages
+    // and the stages of the cells within reach, nothing else; every row left out has a true
+    // distance above every bound the refine certificate uses, so the result stays exact.
+    if constexpr (DIAG_) {
+        if ((ablate & 64) && prune.qpd != nullptr && home != nullptr && T > 0 && T < 65535) {
+            __shared__ float reach_s[NW_ * 32];
+            __shared__ int qrow_s[NW_ * 32];
+            __shared__ unsigned cellmask[8];
+            __shared__ int n_keep;
+            float part = 0.0f;
+#pragma unroll
+            for (int c = 0; c < D2P; ++c) part = fmaf(0.25f * qf[c], qf[c], part);  // qf holds -2 q
+            const float qn = part + __shfl_xor(part, 32);
+            const float rmax2 = __uint_as_float(*prune.maxnorm) * 1.00001f;
+            float reach = -__builtin_inff();  // padding queries need nothing
+            if (q0 + j < n) {
+                const float t2 = (tau + qn + prune.err_coef * (rmax2 + qn)) * 1.00001f;
+                reach = tau < tau_max ? sqrtf(fmaxf(t2, 0.0f)) * 1.000001f : __builtin_inff();
+            }
+            if (hh == 0) {
+                reach_s[wave * 32 + j] = reach;
+                qrow_s[wave * 32 + j] = (q0 + j < n) ? prune.perm_q[q0 + j] : -1;
+            }
+            if (tid < 8) cellmask[tid] = 0u;
+            __syncthreads();
+            constexpr int QPB = NW_ * 32;
+            const int C = prune.cells;
+            for (int idx = tid; idx < C * QPB; idx += NW_ * 64) {
+                const int c = idx / QPB, ql = idx - c * QPB;
+                const int qrow = qrow_s[ql];
+                bool need = false;
+                if (qrow >= 0) {
+                    const float dq = prune.qpd[(long long)c * prune.n + qrow];
+                    const float rho = __uint_as_float(prune.crad[c]);
+                    need = !((dq - rho) * 0.99999f > reach_s[ql]);  // (NaN anywhere: the cell stays)
+                }
+                // (a wave's 64 pairs share the cell or straddle two of them: QPB is a multiple of 64)
+                if (__any(need) && lane == 0) atomicOr(&cellmask[c >> 5], 1u << (c & 31));
+            }
+            __syncthreads();
+            // the stages of the cells within reach, in ascending order, without the home stages
+            unsigned short* my_order = prune.order + (long long)blockIdx.x * prune.order_stride;
+            if (tid == 0) {
+                int cnt = 0, last = -1;
+                for (int c = 0; c < C; ++c) {
+                    if (!((cellmask[c >> 5] >> (c & 31)) & 1u)) continue;
+                    const long long a = prune.cstart_r[c], b = prune.cstart_r[c + 1];
+                    if (b <= a) continue;
+                    int g0 = (int)(a / RT) - G0, g1 = (int)((b - 1) / RT) - G0;
+                    if (g0 <= last) g0 = last + 1;  // (cells follow each other: a stage can belong to two)
+                    if (g0 < 0) g0 = 0;
+                    if (g1 >= T) g1 = T - 1;
+                    for (int g = g0; g <= g1; ++g) {
+                        if (oN > 0 && g >= O0 - G0 && g < O0 - G0 + oN) continue;
+                        my_order[cnt++] = (unsigned short)g;
+                    }
+                    if (g1 > last) last = g1;
+                }
+                n_keep = cnt;
+            }
+            __syncthreads();
+            order = my_order;
+            T_loop = oN + n_keep;
+        }
+    }
+    const int T_run = T_loop;
+
     {   // Two stage buffers, one block barrier per stage.
-        if (T > 0) SCMIAC_STAGE(stage_row(0), 0);
+        if (T_run > 0) SCMIAC_STAGE(stage_row(0), 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        for (int t = 0; t < T; ++t) {
-            if (do_stage && t + 1 < T) SCMIAC_STAGE(stage_row(t + 1), (t + 1) & 1);
+        for (int t = 0; t < T_run; ++t) {
+            if (do_stage && t + 1 < T_run) SCMIAC_STAGE(stage_row(t + 1), (t + 1) & 1);
             const float* tb = tile + (do_stage ? (t & 1) : 0) * RT * LS;
             const float* nb = tnorm + (do_stage ? (t & 1) : 0) * RT;
             const long long cur_row0 = stage_row(t);
@@ -453,7 +532,7 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
             if (do_sync) __syncthreads();
         }
     }
-    if (T > 0) {  // the last subtile is still untested
+    if (T_run > 0) {  // the last subtile is still untested
         float mn_ = accs[1][0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) mn_ = fminf(mn_, accs[1][r]);
@@ -477,7 +556,7 @@ template <int D2, int NW, int RT, int PC, bool GP, bool DIAG>
 hipError_t launch_fused_t(const float* Qp, const float* Rp, const float* rnorm, u64* lists, uint2* pend_g,
                                  long long n, long long n_pad, int nqb, int S, long long chunk_rows,
                                  const FusedTail& tail, int kt, int ablate, const int* home, int seed_stages,
-                                 const float* tau0, float* tau_out, u64* diag, hipStream_t stream) {
+                                 const float* tau0, float* tau_out, const PruneArgs& prune, u64* diag, hipStream_t stream) {
     using C = FusedCfg<D2, NW, RT, PC, GP>;
     size_t lds = C::lds_bytes();
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_knn_kernel<D2, NW, RT, PC, GP, DIAG>),
@@ -485,7 +564,7 @@ hipError_t launch_fused_t(const float* Qp, const float* Rp, const float* rnorm, 
     if (e != hipSuccess) return e;
     dim3 grid((unsigned)(tail.block0 + (nqb - tail.qb0) * tail.St)), block(NW * 64);
     hipLaunchKernelGGL((fused_knn_kernel<D2, NW, RT, PC, GP, DIAG>), grid, block, lds, stream, Qp, Rp, rnorm, lists, pend_g, n,
-                       n_pad, nqb, chunk_rows, tail, kt, ablate, home, seed_stages, tau0, tau_out, diag);
+                       n_pad, nqb, chunk_rows, tail, kt, ablate, home, seed_stages, tau0, tau_out, prune, diag);
     return hipGetLastError();
 }
 
@@ -526,10 +605,10 @@ int fused_occupancy_t() {
     if (g.D2 == V_ && g.nw == NW_ && g.RT == RT_ && g.pcap == PC_ && g.gp == GP_)                                      \
         return diag_inst ? launch_fused_t<V_, NW_, RT_, PC_, (GP_ != 0), true>(                                        \
                                a.Qp, a.Rp, a.rnorm, a.lists, static_cast<uint2*>(a.pend_g), a.n, g.n_pad, g.nqb, g.S, g.chunk_rows, g.tail, \
-                               a.kt, a.ablate, a.home, g.seed_stages, a.tau0, a.tau_out, a.diag, a.stream)             \
+                               a.kt, a.ablate, a.home, g.seed_stages, a.tau0, a.tau_out, a.prune, a.diag, a.stream)             \
                          : launch_fused_t<V_, NW_, RT_, PC_, (GP_ != 0), false>(                                       \
                                a.Qp, a.Rp, a.rnorm, a.lists, static_cast<uint2*>(a.pend_g), a.n, g.n_pad, g.nqb, g.S, g.chunk_rows, g.tail, \
-                               a.kt, 0, a.home, g.seed_stages, a.tau0, a.tau_out, a.diag, a.stream);
+                               a.kt, 0, a.home, g.seed_stages, a.tau0, a.tau_out, PruneArgs{}, a.diag, a.stream);
 #define SCMIAC_TU_OCC_CASE(V_, NW_, RT_, PC_, GP_)                                                                     \
     if (g.D2 == V_ && g.nw == NW_ && g.RT == RT_ && g.pcap == PC_ && g.gp == GP_)                                      \
         return fused_occupancy_t<V_, NW_, RT_, PC_, (GP_ != 0)>();

@@ -46,6 +46,7 @@ struct KnnGeometry {
     int cells_pad;         // cells rounded up to a multiple of 8
     int home_max;          // most home stages a query block streams ahead of its chunk
     int seed_stages;       // home stages the fused kernel's seed pass looks at
+    int prune;             // 1: experimental exact pruning by the partition's pivots (tuning bit 64)
 };
 
 // device scratch of the locality partition (carved out of the search workspace)
@@ -61,6 +62,10 @@ struct LocalityWs {
     int* perm_q;            // [n]: packed query position -> caller's row
     int* perm_r;            // [m]: packed reference row -> caller's row
     int* home;              // [nqb][2]
+    // pruning experiment only (NULL otherwise)
+    float* qpd;             // [cells_pad][n]: lower bound of dist(query row, pivot)
+    unsigned* crad;         // [cells_pad]: float bits, upper bound of max dist(reference row, its pivot)
+    unsigned short* order;  // [grid blocks][stages of a chunk]: the stages a block decided to stream
 };
 
 // Diagnostic / tuning knobs of the fused kernel's grid plan (all zero = product behaviour).
@@ -92,6 +97,21 @@ inline int knn_threshold_rank(int k, int d) {
 }
 KnnGeometry knn_geometry(long long n, long long m, int d, int k, int splits);
 
+// Pruning experiment (diagnostic instantiation, tuning bit 64): what the fused kernel needs to
+// decide, per block, which cells of the reference image can hold a neighbour of its queries.
+struct PruneArgs {
+    const float* qpd;          // NULL: no pruning
+    long long n;               // row stride of qpd
+    const unsigned* crad;
+    const int* cstart_r;       // [cells + 1] first packed row of every cell
+    const int* perm_q;         // packed query position -> caller's row
+    const unsigned* maxnorm;   // max |r|^2 (float bits)
+    float err_coef;            // |score + |q|^2 - T| <= err_coef (|r|^2 + |q|^2)
+    int cells;
+    unsigned short* order;     // [grid blocks][order_stride]
+    int order_stride;
+};
+
 // arguments of one launch of the fused kernel that are not part of the geometry
 struct FusedLaunch {
     const float* Qp;
@@ -105,6 +125,7 @@ struct FusedLaunch {
     const int* home;
     const float* tau0;
     float* tau_out;
+    PruneArgs prune;
     unsigned long long* diag;
     hipStream_t stream;
 };
@@ -126,9 +147,11 @@ hipError_t launch_locality(const float* Q, long long n, const float* R, long lon
                            const LocalityWs& w, hipStream_t stream);
 hipError_t launch_seed_tau(const float* Q, const int* perm_q, int d, long long n, const KnnGeometry& g, const int* idx,
                            const float* d2, int k, const unsigned* maxnorm_bits, float* tau0, hipStream_t stream);
+// the pruning experiment's kernel arguments (qpd == NULL unless the geometry asks for it)
+PruneArgs knn_prune_args(const KnnGeometry& g, const LocalityWs& loc, const unsigned* maxnorm, long long n, int d);
 hipError_t launch_fused(const KnnGeometry& g, const float* Qp, const float* Rp, const float* rnorm,
                         unsigned long long* lists, void* pend_g, long long n, int kt, const int* home,
-                        const float* tau0, float* tau_out, unsigned long long* diag, hipStream_t stream);
+                        const float* tau0, float* tau_out, const PruneArgs& prune, unsigned long long* diag, hipStream_t stream);
 hipError_t launch_refine(const float* Q, const float* Qp, const float* Rp, int d, long long n, const KnnGeometry& g,
                          const unsigned long long* lists, int k, int kt, long long col_offset, int merge,
                          const unsigned* maxnorm_bits, const float* tau_lists, const int* perm_q, const int* perm_r,

@@ -106,13 +106,66 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict_
 static constexpr int CELL_ROWS = 256;     // rows per block of the partition kernels
 static constexpr int CELL_TP = 8;         // pivots scored together per thread
 
-// pivT[i][c] = feature i of pivot c (= row (c * m) / C of R), pnorm[c] = |pivot c|^2
+// Pruning experiment: pivots by farthest-point traversal over a sample of the reference rows (each
+// new pivot is the sample row farthest from all pivots so far), so that every cluster of the data
+// gets pivots of its own and no cell has to take in the rows of a cluster without one: the cells'
+// radii, which the pruning bound subtracts, stay at the size of a cluster.  One block; sample row
+// s is row s * m / FPS_SAMPLE of R.
+static constexpr int FPS_SAMPLE = 8192, FPS_NT = 1024, FPS_PER = FPS_SAMPLE / FPS_NT;
+__global__ __launch_bounds__(FPS_NT) void fps_pivots_kernel(const float* __restrict__ R, long long m, int d, int C,
+                                                            int* __restrict__ piv_rows) {
+    __shared__ float pv[SCMIAC_KNN_MAX_D_INTERNAL];
+    __shared__ float red_v[FPS_NT / 64];
+    __shared__ int red_i[FPS_NT / 64];
+    __shared__ int cur;
+    const int tid = threadIdx.x;
+    const long long S = m < FPS_SAMPLE ? m : FPS_SAMPLE;
+    float mind[FPS_PER];
+#pragma unroll
+    for (int u = 0; u < FPS_PER; ++u) mind[u] = __builtin_inff();
+    if (tid == 0) { cur = 0; piv_rows[0] = 0; }
+    __syncthreads();
+    for (int c = 1; c <= C; ++c) {
+        const long long prow = (long long)cur * m / S;
+        for (int i = tid; i < d; i += FPS_NT) pv[i] = R[prow * d + i];
+        __syncthreads();
+        float best = -1.0f;
+        int besti = 0;
+#pragma unroll
+        for (int u = 0; u < FPS_PER; ++u) {
+            const long long sidx = (long long)u * FPS_NT + tid;
+            if (sidx < S) {
+                const float* row = R + (sidx * m / S) * d;
+                float acc = 0.0f;
+                for (int i = 0; i < d; ++i) { const float t = row[i] - pv[i]; acc = __fmaf_rn(t, t, acc); }
+                mind[u] = fminf(mind[u], acc == acc ? acc : 0.0f);  // (NaN rows never become pivots)
+                if (mind[u] > best) { best = mind[u]; besti = (int)sidx; }
+            }
+        }
+        for (int off = 32; off; off >>= 1) {
+            const float ov = __shfl_xor(best, off);
+            const int oi = __shfl_xor(besti, off);
+            if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+        }
+        if ((tid & 63) == 0) { red_v[tid >> 6] = best; red_i[tid >> 6] = besti; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < FPS_NT / 64; ++w)
+                if (red_v[w] > best || (red_v[w] == best && red_i[w] < besti)) { best = red_v[w]; besti = red_i[w]; }
+            cur = besti;
+            if (c < C) piv_rows[c] = (int)((long long)besti * m / S);
+        }
+        __syncthreads();
+    }
+}
+
+// pivT[i][c] = feature i of pivot c (= row (c * m) / C of R, or row piv_rows[c]), pnorm[c] = |pivot c|^2
 __global__ void pivots_kernel(const float* __restrict__ R, long long m, int d, int C, int Cpad,
-                              float* __restrict__ pivT, float* __restrict__ pnorm) {
+                              float* __restrict__ pivT, float* __restrict__ pnorm, const int* __restrict__ piv_rows) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= Cpad) return;
     float acc = 0.0f;
-    const float* row = R + ((long long)c * m / C) * d;
+    const float* row = R + (piv_rows != nullptr && c < C ? (long long)piv_rows[c] : (long long)c * m / C) * d;
     for (int i = 0; i < d; ++i) {
         const float v = c < C ? row[i] : 0.0f;
         pivT[i * Cpad + c] = v;
@@ -127,7 +180,9 @@ __global__ __launch_bounds__(CELL_ROWS) void assign_cells_kernel(const float* __
                                                                  const float* __restrict__ pivT,
                                                                  const float* __restrict__ pnorm, int C, int Cpad,
                                                                  unsigned char* __restrict__ cell,
-                                                                 int* __restrict__ blockhist) {
+                                                                 int* __restrict__ blockhist,
+                                                                 float* __restrict__ qpd /* [Cpad][n] or NULL */,
+                                                                 unsigned* __restrict__ crad /* [Cpad] or NULL */) {
     extern __shared__ __attribute__((aligned(16))) float csm[];
     float* pT = csm;                       // [d][Cpad]
     float* pn = pT + d * Cpad;             // [Cpad]
@@ -147,6 +202,11 @@ __global__ __launch_bounds__(CELL_ROWS) void assign_cells_kernel(const float* __
     if (tid < nrows) {
         float best = __builtin_inff();
         int bestc = 0;
+        // (pruning experiment) |x|^2, to turn the scores |p|^2 - 2 x.p into distances with a
+        // rounding-error slack: the float32 chain is off by at most about 8e-6 (|p|^2 + |x|^2)
+        float xn = 0.0f;
+        if (qpd != nullptr || crad != nullptr)
+            for (int i = 0; i < d; ++i) { const float x = xT[i * (CELL_ROWS + 1) + tid]; xn = __fmaf_rn(x, x, xn); }
         for (int c0 = 0; c0 < Cpad; c0 += CELL_TP) {
             float acc[CELL_TP];
 #pragma unroll
@@ -163,8 +223,21 @@ __global__ __launch_bounds__(CELL_ROWS) void assign_cells_kernel(const float* __
 #pragma unroll
             for (int u = 0; u < CELL_TP; ++u)
                 if (acc[u] < best) { best = acc[u]; bestc = c0 + u; }  // NaN rows stay in cell 0
+            if (qpd != nullptr) {
+#pragma unroll
+                for (int u = 0; u < CELL_TP; ++u) {  // a lower bound of the distance to pivot c0 + u
+                    const float slack = 1.6e-5f * (pn[c0 + u] + xn);
+                    const float lo2 = acc[u] + xn - slack;
+                    qpd[(long long)(c0 + u) * n + row0 + tid] = lo2 > 0.0f ? sqrtf(lo2) * 0.999999f : 0.0f;
+                }
+            }
         }
         if (bestc >= C) bestc = 0;
+        if (crad != nullptr) {  // an upper bound of this row's distance to its own pivot
+            const float hi2 = best + xn + 1.6e-5f * (pn[bestc] + xn);
+            const float hi = hi2 > 0.0f ? sqrtf(hi2) * 1.000001f : 0.0f;  // (NaN rows: inf, their cell is never pruned)
+            atomicMax(crad + bestc, __float_as_uint(hi == hi ? hi : __builtin_inff()));
+        }
         cell[row0 + tid] = (unsigned char)bestc;
         atomicAdd(&hist[bestc], 1);
     }
@@ -616,6 +689,7 @@ KnnGeometry knn_geometry(long long n, long long m, int d, int k, int splits) {
         g.home_max = ((tn.home_rows > 0 ? tn.home_rows : 8192) + g.RT - 1) / g.RT;
         // ... and looks at this many of them for its thresholds
         g.seed_stages = ((tn.seed_rows > 0 ? tn.seed_rows : 3072) + g.RT - 1) / g.RT;
+        g.prune = (tn.ablate & 64) ? 1 : 0;  // experiment: exact pruning by the pivots (diagnostic instantiation)
     }
     g.qpb = g.nw * 32;
     g.n_pad = ((n + g.qpb - 1) / g.qpb) * g.qpb;
@@ -719,7 +793,7 @@ hipError_t launch_pack(const float* X, long long n, int d, const KnnGeometry& g,
 // that orders the rows by (cell, row number) and the first position of every cell.
 static hipError_t launch_cells(const float* X, long long n, int d, const KnnGeometry& g, const float* pivT,
                                const float* pnorm, unsigned char* cell, int* blockhist, int* cell_start, int* perm,
-                               hipStream_t stream) {
+                               float* qpd, unsigned* crad, hipStream_t stream) {
     const int C = g.cells, Cpad = g.cells_pad;
     const int nblk = (int)((n + CELL_ROWS - 1) / CELL_ROWS);
     const size_t lds = sizeof(float) * ((size_t)d * Cpad + Cpad + (size_t)d * (CELL_ROWS + 1)) + sizeof(int) * Cpad;
@@ -727,7 +801,7 @@ static hipError_t launch_cells(const float* X, long long n, int d, const KnnGeom
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(assign_cells_kernel, dim3((unsigned)nblk), dim3(CELL_ROWS), lds, stream, X, n, d, pivT, pnorm, C,
-                       Cpad, cell, blockhist);
+                       Cpad, cell, blockhist, qpd, crad);
     // (the totals pass through the tail of the start array's own allocation: C + 1 .. 2 C + 1)
     int* col_total = cell_start + C + 1;
     hipLaunchKernelGGL(cell_column_scan_kernel, dim3((unsigned)C), dim3(256), 0, stream, blockhist, nblk, C, col_total);
@@ -739,11 +813,17 @@ static hipError_t launch_cells(const float* X, long long n, int d, const KnnGeom
 
 hipError_t launch_locality(const float* Q, long long n, const float* R, long long m, int d, const KnnGeometry& g,
                            const LocalityWs& w, hipStream_t stream) {
+    const int* piv_rows = nullptr;
+    if (g.prune && w.crad != nullptr) {  // (the row numbers pass through the head of the stage-list region)
+        int* rows = reinterpret_cast<int*>(w.order);
+        hipLaunchKernelGGL(fps_pivots_kernel, dim3(1), dim3(FPS_NT), 0, stream, R, m, d, g.cells, rows);
+        piv_rows = rows;
+    }
     hipLaunchKernelGGL(pivots_kernel, dim3((unsigned)((g.cells_pad + 63) / 64)), dim3(64), 0, stream, R, m, d, g.cells,
-                       g.cells_pad, w.pivT, w.pnorm);
-    hipError_t e = launch_cells(R, m, d, g, w.pivT, w.pnorm, w.cell_r, w.hist_r, w.cstart_r, w.perm_r, stream);
+                       g.cells_pad, w.pivT, w.pnorm, piv_rows);
+    hipError_t e = launch_cells(R, m, d, g, w.pivT, w.pnorm, w.cell_r, w.hist_r, w.cstart_r, w.perm_r, nullptr, w.crad, stream);
     if (e != hipSuccess) return e;
-    e = launch_cells(Q, n, d, g, w.pivT, w.pnorm, w.cell_q, w.hist_q, w.cstart_q, w.perm_q, stream);
+    e = launch_cells(Q, n, d, g, w.pivT, w.pnorm, w.cell_q, w.hist_q, w.cstart_q, w.perm_q, w.qpd, nullptr, stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(home_stages_kernel, dim3((unsigned)((g.nqb + 63) / 64)), dim3(64), 0, stream, w.cell_q, w.perm_q,
                        n, g.qpb, g.nqb, w.cstart_r, g.RT, g.m_pad, g.home_max, w.home);
@@ -769,18 +849,29 @@ hipError_t launch_seed_tau(const float* Q, const int* perm_q, int d, long long n
 
 hipError_t launch_fused(const KnnGeometry& g, const float* Qp, const float* Rp, const float* rnorm,
                         unsigned long long* lists, void* pend_g_, long long n, int kt, const int* home,
-                        const float* tau0, float* tau_out, unsigned long long* diag, hipStream_t stream) {
+                        const float* tau0, float* tau_out, const PruneArgs& prune, unsigned long long* diag,
+                        hipStream_t stream) {
     uint2* pend_g = static_cast<uint2*>(pend_g_);
     // counters (diag) and ablations (tuning bits: 1 no selection, 2 no staging, 4 no barrier,
     // 8 empty candidate path, 16 candidate arithmetic only) live in a separate instantiation
     // of the kernel; the product kernel carries neither
     const int ablate = knn_get_tuning().ablate;
-    const FusedLaunch a{Qp, Rp, rnorm, lists, pend_g, n, kt, ablate, home, tau0, tau_out, diag, stream};
+    const FusedLaunch a{Qp, Rp, rnorm, lists, pend_g, n, kt, ablate, home, tau0, tau_out, prune, diag, stream};
     for (auto launch : {launch_fused_tu0, launch_fused_tu1, launch_fused_tu2, launch_fused_tu3}) {
         const hipError_t e = launch(g, a);
         if (e != hipErrorNotFound) return e;  // hipErrorNotFound: the variant is not that file's
     }
     return hipErrorInvalidValue;
+}
+
+PruneArgs knn_prune_args(const KnnGeometry& g, const LocalityWs& loc, const unsigned* maxnorm, long long n, int d) {
+    PruneArgs a{};
+    if (!g.prune || loc.qpd == nullptr || g.chunk_rows / g.RT >= 65535) return a;
+    double err_abs_coef, rel_keep;
+    knn_error_model(d, g, &err_abs_coef, &rel_keep);
+    a = PruneArgs{loc.qpd, n, loc.crad, loc.cstart_r, loc.perm_q, maxnorm, (float)(err_abs_coef * 1.001), g.cells,
+                  loc.order, (int)(g.chunk_rows / g.RT + 1)};
+    return a;
 }
 
 hipError_t launch_refine(const float* Q, const float* Qp, const float* Rp, int d, long long n, const KnnGeometry& g,

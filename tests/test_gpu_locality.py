@@ -114,3 +114,29 @@ def test_structureless_and_degenerate_inputs():
     Q3 = np.zeros((2500, 8), dtype=np.float32)                    # every query the same point
     R3 = rng.normal(size=(17000, 8)).astype(np.float32)
     _check(Q3, R3, 10)
+
+
+@pytest.mark.parametrize("d,unit", [(50, False), (30, True), (64, True)])
+def test_pivot_pruning_experiment_stays_exact(d, unit, tuning):
+    """Tuning bit 64: farthest-point pivots, and every block streams only the cells within reach
+    of its queries.  Well separated clusters (most cells pruned), overlapping ones, outliers,
+    duplicates, chunks and a tail, and blocks merged one after the other: always the oracle's table."""
+    for spread, C in ((1.0, 40), (4.0, 12)):
+        Q, _ = _clustered(11, 5000, d, C, spread=spread, unit=unit)
+        R, _ = _clustered(12, 70000, d, C, spread=spread, unit=unit)
+        R[100:140] = R[5]                   # duplicates
+        R[::997] *= 3.0                     # outliers far from every cluster
+        Q[:7] = R[5]
+        tuning(ablate=64)
+        _check(Q, R, 30)
+        tuning(ablate=64, slots=8, tail_min_rows=1024)
+        _check(Q[:3300], R, 31)
+        tuning(ablate=64)
+        idx_o, d2_o = oracle.knn_dist2(Q, R, 30)
+        q, st = _dev(Q), None
+        cuts = (0, 25000, 70000)
+        for lo, hi in zip(cuts, cuts[1:]):
+            st = _hip.knn_search(q, _dev(R[lo:hi]), 30, col_offset=lo, state=st)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(st.idx.cpu().numpy(), idx_o)
+        np.testing.assert_array_equal(st.dist2.cpu().numpy(), d2_o)
