@@ -449,8 +449,18 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
     // the block's queries cannot hold one of their neighbours.  The block streams its home stages
     // and the stages of the cells within reach, nothing else; every row left out has a true
     // distance above every bound the refine certificate uses, so the result stays exact.
-    if constexpr (DIAG_) {
-        if ((ablate & 64) && prune.qpd != nullptr && home != nullptr && T > 0 && T < 65535) {
+    // It happens in two steps, because the queries of a block can belong to two cells while its
+    // home stages (at most 8 192 rows) may cover only part of the first: the queries of the
+    // second would then still carry a loose threshold and keep every cell.  Step 1 (before the
+    // stage loop, no test): after the home stages the block streams the rest of its queries' own
+    // cells.  Step 2 (when those are nearly done and every query has met its own cell): the reach
+    // test decides which other cells follow.
+    bool pruning = false;
+    int replan_at = -1;          // iteration at whose start step 2 runs
+    int own_lo = 0, own_hi = -1; // chunk-relative stages of the queries' own cells
+    unsigned short* my_order = nullptr;
+    auto plan_rest = [&]() __attribute__((always_inline)) {  // step 2; every thread of the block calls it
+        if constexpr (DIAG_) {
             __shared__ float reach_s[NW_ * 32];
             __shared__ int qrow_s[NW_ * 32];
             __shared__ unsigned cellmask[8];
@@ -486,10 +496,10 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
                 if (__any(need) && lane == 0) atomicOr(&cellmask[c >> 5], 1u << (c & 31));
             }
             __syncthreads();
-            // the stages of the cells within reach, in ascending order, without the home stages
-            unsigned short* my_order = prune.order + (long long)blockIdx.x * prune.order_stride;
+            // the stages of the cells within reach, ascending, without the home stages and the own cells'
+            const int done = T_loop - oN;  // entries of the list already there (step 1)
             if (tid == 0) {
-                int cnt = 0, last = -1;
+                int cnt = done, last = -1;
                 for (int c = 0; c < C; ++c) {
                     if (!((cellmask[c >> 5] >> (c & 31)) & 1u)) continue;
                     const long long a = prune.cstart_r[c], b = prune.cstart_r[c + 1];
@@ -500,6 +510,7 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
                     if (g1 >= T) g1 = T - 1;
                     for (int g = g0; g <= g1; ++g) {
                         if (oN > 0 && g >= O0 - G0 && g < O0 - G0 + oN) continue;
+                        if (g >= own_lo && g <= own_hi) continue;
                         my_order[cnt++] = (unsigned short)g;
                     }
                     if (g1 > last) last = g1;
@@ -507,18 +518,53 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
                 n_keep = cnt;
             }
             __syncthreads();
-            order = my_order;
             T_loop = oN + n_keep;
         }
+    };
+    if constexpr (DIAG_) {
+        if ((ablate & 64) && prune.qpd != nullptr && home != nullptr && T > 0 && T < 65535) {
+            __shared__ int n_own, s_lo, s_hi;
+            my_order = prune.order + (long long)blockIdx.x * prune.order_stride;
+            if (tid == 0) {
+                // the block's queries are consecutive in the packed order, i.e. sorted by cell
+                const long long qa = (long long)qb * (NW_ * 32);
+                long long qz = qa + NW_ * 32 - 1;
+                if (qz >= n) qz = n - 1;
+                int cnt = 0, lo = 0, hi = -1;
+                if (qa < n) {
+                    const int c_lo = prune.cell_q[prune.perm_q[qa]], c_hi = prune.cell_q[prune.perm_q[qz]];
+                    const long long a = prune.cstart_r[c_lo], b = prune.cstart_r[c_hi + 1];
+                    if (b > a) {
+                        lo = (int)(a / RT) - G0;
+                        hi = (int)((b - 1) / RT) - G0;
+                        if (lo < 0) lo = 0;
+                        if (hi >= T) hi = T - 1;
+                        for (int g = lo; g <= hi; ++g) {
+                            if (oN > 0 && g >= O0 - G0 && g < O0 - G0 + oN) continue;
+                            my_order[cnt++] = (unsigned short)g;
+                        }
+                    }
+                }
+                n_own = cnt; s_lo = lo; s_hi = hi;
+            }
+            __syncthreads();
+            own_lo = s_lo; own_hi = s_hi;
+            order = my_order;
+            T_loop = oN + n_own;
+            pruning = true;
+            if (T_loop == 0) plan_rest();       // nothing of its own in this chunk: decide at once
+            else replan_at = T_loop - 1;        // ... else while the last own stage is being fetched
+        }
     }
-    const int T_run = T_loop;
+
 
     {   // Two stage buffers, one block barrier per stage.
-        if (T_run > 0) SCMIAC_STAGE(stage_row(0), 0);
+        if (T_loop > 0) SCMIAC_STAGE(stage_row(0), 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        for (int t = 0; t < T_run; ++t) {
-            if (do_stage && t + 1 < T_run) SCMIAC_STAGE(stage_row(t + 1), (t + 1) & 1);
+        for (int t = 0; t < T_loop; ++t) {
+            if (DIAG_ && pruning && t == replan_at) plan_rest();
+            if (do_stage && t + 1 < T_loop) SCMIAC_STAGE(stage_row(t + 1), (t + 1) & 1);
             const float* tb = tile + (do_stage ? (t & 1) : 0) * RT * LS;
             const float* nb = tnorm + (do_stage ? (t & 1) : 0) * RT;
             const long long cur_row0 = stage_row(t);
@@ -532,7 +578,7 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
             if (do_sync) __syncthreads();
         }
     }
-    if (T_run > 0) {  // the last subtile is still untested
+    if (T_loop > 0) {  // the last subtile is still untested
         float mn_ = accs[1][0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) mn_ = fminf(mn_, accs[1][r]);

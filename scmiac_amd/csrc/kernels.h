@@ -105,6 +105,7 @@ struct PruneArgs {
     const unsigned* crad;
     const int* cstart_r;       // [cells + 1] first packed row of every cell
     const int* perm_q;         // packed query position -> caller's row
+    const unsigned char* cell_q;  // cell of every query (caller's rows)
     const unsigned* maxnorm;   // max |r|^2 (float bits)
     float err_coef;            // |score + |q|^2 - T| <= err_coef (|r|^2 + |q|^2)
     int cells;

@@ -869,7 +869,7 @@ PruneArgs knn_prune_args(const KnnGeometry& g, const LocalityWs& loc, const unsi
     if (!g.prune || loc.qpd == nullptr || g.chunk_rows / g.RT >= 65535) return a;
     double err_abs_coef, rel_keep;
     knn_error_model(d, g, &err_abs_coef, &rel_keep);
-    a = PruneArgs{loc.qpd, n, loc.crad, loc.cstart_r, loc.perm_q, maxnorm, (float)(err_abs_coef * 1.001), g.cells,
+    a = PruneArgs{loc.qpd, n, loc.crad, loc.cstart_r, loc.perm_q, loc.cell_q, maxnorm, (float)(err_abs_coef * 1.001), g.cells,
                   loc.order, (int)(g.chunk_rows / g.RT + 1)};
     return a;
 }
