@@ -111,7 +111,7 @@ static constexpr int CELL_TP = 8;         // pivots scored together per thread
 // gets pivots of its own and no cell has to take in the rows of a cluster without one: the cells'
 // radii, which the pruning bound subtracts, stay at the size of a cluster.  One block; sample row
 // s is row s * m / FPS_SAMPLE of R.
-static constexpr int FPS_SAMPLE = 8192, FPS_NT = 1024, FPS_PER = FPS_SAMPLE / FPS_NT;
+static constexpr int FPS_SAMPLE = 4096, FPS_NT = 1024, FPS_PER = FPS_SAMPLE / FPS_NT;
 __global__ __launch_bounds__(FPS_NT) void fps_pivots_kernel(const float* __restrict__ R, long long m, int d, int C,
                                                             int* __restrict__ piv_rows) {
     __shared__ float pv[SCMIAC_KNN_MAX_D_INTERNAL];
