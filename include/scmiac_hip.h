@@ -178,11 +178,11 @@ SCMIAC_API int scmiac_anchor_filter(const int64_t *pairs, const int64_t *n_pairs
  *   tail_min_rows  > 0: shortest reference chunk the planner may choose (default 8192)
  *   no_tail        1: do not split the last round's query blocks further
  *   ablate         ablation bits honoured by the diagnostic kernel instantiation only
- *                  (bit 64 is no ablation but an experiment: exact pruning by the partition's
- *                  pivots -- a block streams only the cells within reach of its queries; the
- *                  tables stay identical, the dense contraction is no longer performed)
  *                  (1 no selection, 2 no staging, 4 no barrier, 8 empty candidate path,
- *                  16 candidate arithmetic only): results are then NOT a k-NN table
+ *                  16 candidate arithmetic only): results are then NOT a k-NN table.
+ *                  Bit 64 is no ablation but an experiment: exact pruning by the partition's
+ *                  pivots -- a block streams only the cells within reach of its queries; the
+ *                  tables stay identical, the dense contraction is no longer performed
  *   diag           1: per-wave counters, see scmiac_knn_diag_region
  *   nw, rt, pcap, gp  kernel variant (waves per block, rows per LDS stage, pending
  *                  candidates per query, 1 = pending buffers in global memory); all zero
