@@ -145,6 +145,38 @@ class _NoComputeBackend:
         return st
 
 
+def host_cores():
+    """Host cores the CPU baseline runs on: the process's affinity mask, bounded by the cgroup's
+    CPU quota where one is set.  An ``OMP_NUM_THREADS`` above 1 is the operator's stated share of a
+    machine whose mask shows every core, and bounds the count too; a value of 1 is what
+    ``torch.distributed.run`` gives each of several workers by default and is NOT taken for the
+    size of the host."""
+    cores = len(os.sched_getaffinity(0))
+    try:  # cgroup v2: "<quota> <period>" or "max <period>"
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()[:2]
+        if quota != "max":
+            cores = min(cores, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    try:
+        stated = int(os.environ.get("OMP_NUM_THREADS", "0"))
+    except ValueError:
+        stated = 0
+    if stated > 1:
+        cores = min(cores, stated)
+    return max(cores, 1)
+
+
+def device_identity(dev, dry):
+    """What tells this rank's GPU from every other one of the node: uuid and PCI address."""
+    if dry:
+        return {"device": f"cpu (rank {os.environ.get('RANK', '0')})", "id": None}
+    p = torch.cuda.get_device_properties(dev)
+    pci = "%04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", 0), getattr(p, "pci_device_id", 0))
+    uuid = str(getattr(p, "uuid", "")) or None
+    return {"device": f"cuda:{dev.index} {p.name} pci {pci}", "id": f"{socket.gethostname()}/{uuid or pci}"}
+
+
 def _dry_backend():
     spec = os.environ.get("SCMIAC_BENCH_DRY_BACKEND")  # "module:attribute", injected by the CPU tests
     if not spec:
@@ -153,23 +185,33 @@ def _dry_backend():
     return getattr(importlib.import_module(mod), attr)()
 
 
-def stored_traffic(workload, n_local, kernel_name):
-    """HBM bytes per launch of the fused kernel from a stored counter profile -- only when that
-    profile was taken on this workload, this launch's kernel instantiation and these kernel
-    sources; ``(None, reason)`` otherwise.  It is never measured in the bench run itself."""
-    tfile = ROOT / "profiles" / "fused_knn_hbm_traffic.json"
-    try:
-        rec = json.loads(tfile.read_text())
-    except Exception:
+def stored_traffic(workload, n_local, m_local, kernel_name):
+    """HBM bytes per launch of the fused kernel from a stored counter profile -- only when a
+    profile under ``profiles/`` was taken on this workload, this many query and reference rows per
+    launch, this launch's kernel instantiation and these kernel sources; ``(None, reason)``
+    otherwise.  It is never measured in the bench run itself."""
+    files = sorted((ROOT / "profiles").glob("*hbm_traffic.json"))
+    if not files:
         return None, "no stored counter profile"
-    if rec.get("workload") != workload or rec.get("n_local") != n_local:
-        return None, "stored profile is of another workload"
-    if rec.get("kernel", "").replace("scmiac::", "") != kernel_name:
-        return None, f"stored profile is of {rec.get('kernel')}, this run launched {kernel_name}"
-    if rec.get("source_sha256") != kernel_source_hash():
-        return None, "kernel sources changed since the stored profile was taken"
-    return rec.get("hbm_bytes_per_launch"), (f"stored rocprofv3 --pmc profile {tfile.relative_to(ROOT)} "
-                                             f"({rec.get('kernel')}), not measured in this run")
+    want_hash, reason = kernel_source_hash(), "no stored profile of this workload and shard size"
+    for tfile in files:
+        try:
+            rec = json.loads(tfile.read_text())
+        except Exception:
+            continue
+        if rec.get("workload") != workload or rec.get("n_local") != n_local:
+            continue
+        if rec.get("m_local") not in (None, m_local):
+            continue
+        if rec.get("kernel", "").replace("scmiac::", "") != kernel_name:
+            reason = f"stored profile {tfile.name} is of {rec.get('kernel')}, this run launched {kernel_name}"
+            continue
+        if rec.get("source_sha256") != want_hash:
+            reason = f"kernel sources changed since the stored profile {tfile.name} was taken"
+            continue
+        return rec.get("hbm_bytes_per_launch"), (f"stored rocprofv3 --pmc profile {tfile.relative_to(ROOT)} "
+                                                 f"({rec.get('kernel')}), not measured in this run")
+    return None, reason
 
 
 def kernel_source_hash():
@@ -189,6 +231,8 @@ def main():
     ap.add_argument("--m", type=int, default=None, help="override the number of reference cells")
     ap.add_argument("--k", type=int, default=30)
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU baseline sample (0 = auto: about 15 s of CPU work)")
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="threads of the CPU baseline (0 = every host core this process may use, see host_cores)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline / parity sample")
     ap.add_argument("--no-full", action="store_true", help="skip the full four-table anchor search timing")
     ap.add_argument("--ring", action="store_true",
@@ -239,6 +283,17 @@ def main():
             else:
                 dist.init_process_group("nccl", device_id=dev)
             dist.barrier()  # the communicator exists from here on
+        # evidence that the ranks sit on distinct GPUs (RCCL itself refuses two ranks on one device)
+        ident = device_identity(dev, dry)
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
+        ids = [i["id"] for i in idents]
+        if not dry and len(set(ids)) != world:
+            raise SystemExit(f"rank {rank}: the {world} ranks do not sit on {world} distinct GPUs: {ids}")
+        launch_info = {"backend": dist.get_backend(), "world": dist.get_world_size(),
+                       "devices": [i["device"] for i in idents]}
+    else:
+        launch_info = {"backend": None, "world": 1, "devices": [device_identity(dev, dry)["device"]]}
 
     U, V, l1, l2, d = make_latents(args.workload, args.n, args.m)
     n, m, k = U.shape[0], V.shape[0], args.k
@@ -309,7 +364,10 @@ def main():
         fused_avg_ms = fused_total_ms / max(fused_launches, 1)
         achieved = flops / (fused_avg_ms * 1e-3) / 1e12
         kernel_name = _hip.knn_kernel_name(n_local, r_hi - r_lo, d, k)
-        traffic, traffic_source = stored_traffic(args.workload if not (args.n or args.m) else None, n_local, kernel_name)
+        # (a stored profile describes a workload's own row counts: an overridden --n / --m has none,
+        # a rank's shard of the workload's rows has one when it was profiled as `--n <shard>`)
+        traffic, traffic_source = stored_traffic(args.workload if m == WORKLOADS[args.workload][1] else None,
+                                                 n_local, r_hi - r_lo, kernel_name)
         roofline = {"bound": "mfma", "kernel": kernel_name, "achieved": round(achieved, 2),
                     "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                     "traffic": traffic, "traffic_source": traffic_source,
@@ -325,12 +383,13 @@ def main():
                                f"Gaussian-mixture latents, d={d}, k={k}",
                    "sharding": ("query and reference rows sharded, reference blocks passed round the ring, all-gather of the tables" if args.ring
                                 else "query rows sharded, references replicated, all-gather of the tables" if distributed else "single GPU"),
-                   "uncertified_rows_last_step": int(st.n_uncertified.item())},
+                   "uncertified_rows_last_step": int(st.n_uncertified.item()),
+                   "backend": launch_info["backend"], "world": launch_info["world"], "devices": launch_info["devices"]},
         "roofline": roofline,
     }
     if dry:
         out.update(dry_launch=True, value=None, ms_per_step=None, data="none (launch rehearsal on the CPU)")
-        out["config"]["backend"] = type(backend).__name__
+        out["config"]["search_backend"] = type(backend).__name__
         out["config"]["table_checksum"] = int(st.gathered.to(torch.int64).sum()) if distributed else int(st.idx.to(torch.int64).sum())
 
     if distributed:  # the gathered table is the shards' tables in rank order
@@ -340,11 +399,13 @@ def main():
         out["pcie_inclusive"] = pcie_inclusive(U, V, k, dev)
 
     if rank == 0 and not args.no_cpu and not dry:
-        out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(U[lo:hi], V, k, st, args.cpu_rows)
+        out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(U[lo:hi], V, k, st, args.cpu_rows,
+                                                                     args.cpu_threads or host_cores())
 
     if rank == 0 and not args.no_full and not distributed and not dry:
         out["pruned_exact_search"] = pruned_search(q_dev, r_dev, k, st)
-        out["full_search"] = full_search(U, V, l1, l2, k, dev, rare=RARE_TYPES if args.workload == "c4" else 0)
+        out["full_search"] = full_search(U, V, l1, l2, k, dev, rare=RARE_TYPES if args.workload == "c4" else 0,
+                                         cpu=out.get("cpu_baseline"))
 
     if distributed:
         dist.barrier()
@@ -370,27 +431,29 @@ def pcie_inclusive(U, V, k, dev):
             "h2d_bytes": int(u.numel() + v.numel()) * 4, "d2h_bytes": int(out.numel()) * 4}
 
 
-def cpu_baseline_and_parity(Q, R, k, st, rows_arg):
-    """Time the CPU oracle on a sample of query rows (all references) and compare
-    the GPU result on those rows."""
+def cpu_baseline_and_parity(Q, R, k, st, rows_arg, cores):
+    """Time the CPU oracle's k-NN search on a sample of query rows (all references), on ``cores``
+    threads, and compare the GPU result on those rows.  (The rest of the anchor search -- mutual
+    nearest neighbours, shared-neighbour counts, min_max, label filter -- is timed on the CPU by
+    :func:`full_search`, which adds it to this object.)"""
     from oracle import oracle  # test infrastructure: checker and reported baseline only
 
     oracle.build()
-    cores = oracle.host_threads()
+    oracle.set_threads(cores)
     rng = np.random.default_rng(12345)
     n = Q.shape[0]
     if rows_arg > 0:
         nrows = min(rows_arg, n)
     else:
         probe = rng.choice(n, size=min(n, 16 * cores), replace=False)
-        oracle.knn_dist2(Q[probe[:cores]], R, k)  # thread pool and caches warm
+        oracle.knn_dist2(Q[probe[:cores]], R, k, nthreads=cores)  # thread pool and caches warm
         t0 = time.perf_counter()
-        oracle.knn_dist2(Q[probe], R, k)
+        oracle.knn_dist2(Q[probe], R, k, nthreads=cores)
         rate = len(probe) / max(time.perf_counter() - t0, 1e-6)
         nrows = int(min(n, max(64, rate * 15.0)))
     rows = np.sort(rng.choice(n, size=nrows, replace=False))
     t0 = time.perf_counter()
-    idx_o, d2_o = oracle.knn_dist2(Q[rows], R, k)
+    idx_o, d2_o = oracle.knn_dist2(Q[rows], R, k, nthreads=cores)
     dt = time.perf_counter() - t0
     rows_t = torch.from_numpy(rows).to(st.idx.device)
     idx_g = st.idx[rows_t].cpu().numpy()
@@ -398,7 +461,9 @@ def cpu_baseline_and_parity(Q, R, k, st, rows_arg):
     bad_rows = int((idx_g != idx_o).any(axis=1).sum())
     cpu = {"value": round(nrows / dt, 2), "unit": "query cells/s", "cores": cores, "kind": "port",
            "sample": f"{nrows} query rows (seeded sample of this rank's shard) against all {R.shape[0]} reference rows, "
-                     f"{dt:.1f} s, exact C/OpenMP oracle of the reference path"}
+                     f"{dt:.1f} s, exact C/OpenMP oracle of the reference path on {cores} threads "
+                     f"(OMP_NUM_THREADS={os.environ.get('OMP_NUM_THREADS', 'unset')}, "
+                     f"{len(os.sched_getaffinity(0))} cores in the affinity mask)"}
     parity = {"rows_checked": nrows, "rows_with_index_mismatch": bad_rows,
               "dist2_bit_identical": bool(np.array_equal(d2_g, d2_o))}
     return cpu, parity
@@ -430,9 +495,12 @@ def pruned_search(q_dev, r_dev, k, dense):
                     "skips most of the dense contraction on clustered data, so it has no MFMA roofline"}
 
 
-def full_search(U, V, l1, l2, k, dev, rare=0):
+def full_search(U, V, l1, l2, k, dev, rare=0, cpu=None):
     """One whole anchor search on the device: four tables, MNN, SNN score, label filter.
-    ``rare`` > 0: labels below it are the rare cell types; report what they keep."""
+    ``rare`` > 0: labels below it are the rare cell types; report what they keep.
+    ``cpu``: the ``cpu_baseline`` object; the oracle's mutual-nearest-neighbour search, shared-neighbour
+    counts, ``min_max`` and label filter are then run on the same four tables on the host, compared
+    with the device's anchors and added to it together with an estimate of the whole search."""
     u, v = torch.from_numpy(U).to(dev), torch.from_numpy(V).to(dev)
     c1, c2 = anchor_search.label_codes(l1, l2)
     c1, c2 = torch.from_numpy(c1).to(dev), torch.from_numpy(c2).to(dev)
@@ -455,7 +523,49 @@ def full_search(U, V, l1, l2, k, dev, rare=0):
                              "anchors_kept_total": int(per_type.sum()), "anchors_kept_per_type_min": int(per_type.min()),
                              "anchors_kept_per_type_median": float(np.median(per_type)),
                              "types_with_no_anchor": int((per_type == 0).sum())}
+    if cpu is not None:
+        res["anchors_identical_to_oracle_on_these_tables"] = cpu_anchor_tail(tables, scores, kept, l1, l2, k, cpu,
+                                                                            U.shape[0], V.shape[0])
     return res
+
+
+def cpu_anchor_tail(tables, scores, kept, l1, l2, k, cpu, n1, n2):
+    """The rest of the reference path after the k-NN tables (anchors.py:569-581, 631-679 and
+    scmiac.py:89-103), on the host with the oracle, on the device's four tables: timed into
+    ``cpu["anchor_tail"]`` and compared with the device's anchors (returns whether all is equal)."""
+    from oracle import oracle  # checker and reported baseline only
+
+    cores = cpu["cores"]
+    oracle.set_threads(cores)
+    G11, G12, G21, G22 = tables.numpy()
+    t0 = time.perf_counter()
+    pairs = oracle.find_mnn(G12, G21, 5)
+    t1 = time.perf_counter()
+    raw = oracle.snn_counts(pairs, G11, G12, G21, G22, min(30, k))
+    t2 = time.perf_counter()
+    import pandas as pd
+    df = pd.DataFrame(pairs.reshape(-1, 2), columns=["x1", "x2"])
+    with np.errstate(all="ignore"):
+        df["score"] = oracle.min_max(raw.astype(np.int64)) if len(raw) else np.empty(0)
+    want = oracle.label_filter(df, l1, l2)
+    t3 = time.perf_counter()
+    same = bool(len(pairs.reshape(-1, 2)) == scores.n
+                and np.array_equal(pairs.reshape(-1, 2), scores.pairs[:scores.n].cpu().numpy())
+                and np.array_equal(raw, scores.raw[:scores.n].cpu().numpy())
+                and np.array_equal(want["x1"].values, kept.x1) and np.array_equal(want["x2"].values, kept.x2)
+                and np.array_equal(want["score"].values, kept.score))
+    tail_s = t3 - t0
+    tables_s = 2.0 * (n1 + n2) / cpu["value"]  # four tables: every cell is a query row twice, at the sampled rate
+    cpu["anchor_tail"] = {"find_mnn_s": round(t1 - t0, 3), "snn_counts_s": round(t2 - t1, 3),
+                          "min_max_label_filter_s": round(t3 - t2, 3), "total_s": round(tail_s, 3),
+                          "raw_anchors": int(len(raw)), "anchors_after_filter": int(len(want)),
+                          "cores": cores,
+                          "note": "oracle find_mnn (serial C loop) + shared-neighbour counts (C/OpenMP) + numpy min_max + "
+                                  "pandas label filter on the four full tables of full_search"}
+    cpu["whole_search"] = {"estimate_s": round(tables_s + tail_s, 1), "cells_per_s": round((n1 + n2) / (tables_s + tail_s), 2),
+                           "note": f"four exact tables at the sampled rate ({2 * (n1 + n2)} query rows / {cpu['value']} rows/s, "
+                                   f"extrapolated) + the measured anchor tail; cells = {n1} + {n2}"}
+    return same
 
 
 if __name__ == "__main__":

@@ -51,6 +51,15 @@ ORACLE_API int oracle_max_threads(void) {
 #endif
 }
 
+/* threads of the parallel loops from now on (those of oracle_knn calls with nthreads <= 0 too) */
+ORACLE_API void oracle_set_threads(int nthreads) {
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+    (void)nthreads;
+#endif
+}
+
 /* (D, idx) lexicographic "less than" */
 static inline int key_less(float da, int64_t ia, float db, int64_t ib) {
     return (da < db) || (da == db && ia < ib);
@@ -177,15 +186,18 @@ static int set_intersection_count(const int32_t *a, const int32_t *b, int ks) {
 ORACLE_API int oracle_snn_score(const int64_t *pairs, int64_t n_anchor, const int32_t *G11,
                                 const int32_t *G12, const int32_t *G21, const int32_t *G22,
                                 int64_t n1, int64_t n2, int64_t ld, int ks, int32_t *score) {
+    int bad = 0;
+    /* anchors are independent of each other: one per loop iteration, any order */
+#pragma omp parallel for schedule(static) reduction(| : bad)
     for (int64_t a = 0; a < n_anchor; ++a) {
         int64_t x = pairs[2 * a], y = pairs[2 * a + 1];
         if (x < 0) x += n1;
         if (y < 0) y += n2;
-        if (x < 0 || x >= n1 || y < 0 || y >= n2) return 1;
+        if (x < 0 || x >= n1 || y < 0 || y >= n2) { bad |= 1; continue; }
         score[a] = set_intersection_count(G11 + x * ld, G21 + y * ld, ks) +
                    set_intersection_count(G12 + x * ld, G22 + y * ld, ks);
     }
-    return 0;
+    return bad;
 }
 
 /*

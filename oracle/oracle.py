@@ -76,6 +76,14 @@ def host_threads() -> int:
     return int(lib.oracle_max_threads())
 
 
+def set_threads(nthreads: int) -> None:
+    """Threads of the C loops (k-NN search, shared-neighbour counts) from now on."""
+    lib = _lib()
+    lib.oracle_set_threads.argtypes = [ctypes.c_int]
+    lib.oracle_set_threads.restype = None
+    lib.oracle_set_threads(int(nthreads))
+
+
 # --------------------------------------------------------------------------- k-NN
 def knn(query, ref, k, nthreads: int = 0):
     """Exact k nearest rows of ``ref`` for every row of ``query``.

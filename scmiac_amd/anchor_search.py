@@ -33,7 +33,8 @@ class NeighborTables:
 
 def knn_table(query, ref, k, *, want_dist=False, splits=0):
     """``index.query(query, k)`` / ``index.neighbor_graph`` for an exact index over ``ref``."""
-    st = _hip.knn_search(query, ref, k, splits=splits)
+    from .wide_knn import knn_any_k  # (imports this package's binding)
+    st = knn_any_k(query, ref, k, splits=splits)
     return (st.idx, st.dist, st) if want_dist else (st.idx, None, st)
 
 
@@ -43,8 +44,8 @@ def find_neighbor_device(cc1, cc2, k):
     the ranks of that group (every rank passes the same ``cc1`` / ``cc2`` and gets the whole tables)."""
     n1, n2 = cc1.shape[0], cc2.shape[0]
     kk = k + 1  # neighbor_graph is built with n_neighbors = k + 1, column 0 dropped
-    if k < 1 or kk > _hip.KNN_MAX_K:
-        raise ValueError(f"k={k} outside 1..{_hip.KNN_MAX_K - 1}")
+    if k < 1:
+        raise ValueError(f"k={k} must be at least 1")
     from . import sharded  # (imports this module)
     if sharded.active_group() is not None:
         return sharded.find_neighbor_sharded(cc1, cc2, k, group=sharded.active_group().group)

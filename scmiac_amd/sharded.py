@@ -100,8 +100,10 @@ def gather_rows_async(local, n, group=None):
 
 
 def knn_replicated(q_local, r_full, k, *, backend=_hip):
-    """This rank's query rows against the whole (replicated) reference set."""
-    return backend.knn_search(q_local, r_full, k)
+    """This rank's query rows against the whole (replicated) reference set (any ``k``: beyond the
+    fused kernel's 64 neighbours per row the search is the group-wise merge of ``wide_knn``)."""
+    from .wide_knn import knn_any_k
+    return knn_any_k(q_local, r_full, k, backend=backend)
 
 
 def _uncertified(state):

@@ -21,10 +21,10 @@ from . import _hip
 _SENTINEL = torch.iinfo(torch.int64).max
 
 
-def _group_keys(q, r_group, g, n_groups):
+def _group_keys(q, r_group, g, n_groups, backend):
     """int64 keys (float32 distance bits << 32 | global row) of q's 64 nearest rows in one group."""
     kk = min(_hip.KNN_MAX_K, r_group.shape[0])
-    st = _hip.knn_search(q, r_group, kk)
+    st = backend.knn_search(q, r_group, kk)
     rows = st.idx.to(torch.int64) * n_groups + g
     keys = (st.dist2.view(torch.int32).to(torch.int64) << 32) | rows
     keys = torch.where(st.idx >= 0, keys, torch.full_like(keys, _SENTINEL))
@@ -34,10 +34,12 @@ def _group_keys(q, r_group, g, n_groups):
     return keys
 
 
-def knn_search_wide(q, r, k, *, n_groups=None, query_chunk=32768):
+def knn_search_wide(q, r, k, *, n_groups=None, query_chunk=32768, backend=_hip):
     """``(idx int32 [n, k], dist2 float32 [n, k], dist float32 [n, k])`` of the k nearest rows
-    of ``r`` for every row of ``q``, ordered by ``(distance, index)``; any ``k <= len(r)``."""
-    _hip.require_gpu()
+    of ``r`` for every row of ``q``, ordered by ``(distance, index)``; any ``k <= len(r)``.
+    ``backend`` supplies ``knn_search`` (the HIP library; a CPU stand-in in the host-logic tests)."""
+    if backend is _hip:
+        _hip.require_gpu()
     device = q.device
     n, m = q.shape[0], r.shape[0]
     if k > m:
@@ -50,7 +52,7 @@ def knn_search_wide(q, r, k, *, n_groups=None, query_chunk=32768):
     d2 = torch.empty((n, k), dtype=torch.float32, device=device)
     for c0 in range(0, n, query_chunk):
         qc = q[c0:c0 + query_chunk]
-        keys = torch.cat([_group_keys(qc, rg, g, n_groups) for g, rg in enumerate(groups)], dim=1)
+        keys = torch.cat([_group_keys(qc, rg, g, n_groups, backend) for g, rg in enumerate(groups)], dim=1)
         top = torch.sort(keys, dim=1).values[:, :k]
         kth = top[:, k - 1:k]
         last = keys[:, _hip.KNN_MAX_K - 1::_hip.KNN_MAX_K]     # 64th key of every group
@@ -64,8 +66,41 @@ def knn_search_wide(q, r, k, *, n_groups=None, query_chunk=32768):
         if bad.numel():
             if max(g.shape[0] for g in groups) <= _hip.KNN_MAX_K:
                 raise AssertionError("complete group lists cannot be cut short")
-            i2, d22, _ = knn_search_wide(qc[bad], r, k, n_groups=2 * n_groups, query_chunk=query_chunk)
+            i2, d22, _ = knn_search_wide(qc[bad], r, k, n_groups=2 * n_groups, query_chunk=query_chunk,
+                                         backend=backend)
             idx[c0 + bad] = i2
             d2[c0 + bad] = d22
     dist = d2.to(torch.float64).sqrt().to(torch.float32)
     return idx, d2, dist
+
+
+class WideState:
+    """Result of :func:`knn_any_k` beyond 64 neighbours, with the members of ``_hip.KnnState`` the
+    callers of a finished search read (the merged result is exact: nothing is left uncertified)."""
+
+    def __init__(self, idx, dist2, dist):
+        self.idx, self.dist2, self.dist = idx, dist2, dist
+        self.n_uncertified = torch.zeros((1,), dtype=torch.int32, device=idx.device)
+        self.uncertified_rows = torch.empty((0,), dtype=torch.int32, device=idx.device)
+        self.blocks = 1
+
+
+def knn_any_k(q, r, k, *, backend=_hip, **search_args):
+    """One exact search for any ``k``: the fused kernel's own 64-neighbour search where that is
+    enough, the group-wise merge beyond (``find_neighbor``'s ``_k = max(k_anchor, k_score)`` is the
+    caller's choice, scmiac/preprocessing/anchors.py:885-886).  A reference set of fewer than ``k``
+    rows pads with -1 / +inf like the narrow search does.  ``search_args`` (``splits``) reach the
+    narrow search only."""
+    if k <= _hip.KNN_MAX_K:
+        return backend.knn_search(q, r, k, **search_args)
+    m = r.shape[0]
+    idx, d2, dist = knn_search_wide(q, r, min(k, m), backend=backend) if m > 0 and q.shape[0] > 0 else (
+        torch.empty((q.shape[0], 0), dtype=torch.int32, device=q.device),
+        torch.empty((q.shape[0], 0), dtype=torch.float32, device=q.device),
+        torch.empty((q.shape[0], 0), dtype=torch.float32, device=q.device))
+    if idx.shape[1] < k:
+        pad = k - idx.shape[1]
+        idx = torch.cat([idx, idx.new_full((idx.shape[0], pad), -1)], dim=1)
+        d2 = torch.cat([d2, d2.new_full((d2.shape[0], pad), float("inf"))], dim=1)
+        dist = torch.cat([dist, dist.new_full((dist.shape[0], pad), float("inf"))], dim=1)
+    return WideState(idx.contiguous(), d2.contiguous(), dist.contiguous())

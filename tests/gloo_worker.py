@@ -147,6 +147,12 @@ def main():
     for got, want in zip(t.numpy(), oracle.find_neighbor(U, V, 12)):
         np.testing.assert_array_equal(got, want)
 
+    # --- the same with more neighbours than one 64-neighbour search returns (k_anchor = 70 makes
+    # find_neighbor's k 70): every table is then the group-wise merge, shard by shard
+    t = sharded.find_neighbor_sharded(torch.from_numpy(U), torch.from_numpy(V), 70, backend=OracleBackend())
+    for got, want in zip(t.numpy(), oracle.find_neighbor(U, V, 70)):
+        np.testing.assert_array_equal(got, want)
+
     # --- the whole search sharded by the rows of the first set: only G21 / G22 are gathered, the
     # anchors of all ranks in rank order are the unsharded (i, j) order
     cases = [(301, 257, 12), (7, 40, 3)] + ([(world - 1, 33, 1)] if world >= 3 else [])   # ragged, tiny, an empty shard

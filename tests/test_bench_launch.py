@@ -61,7 +61,8 @@ def test_ring_mode_over_two_ranks_and_with_a_single_rank():
 def test_gpus_3_no_compute_backend():
     out = _json_line(_run(["--gpus", "3", "--steps", "1", "--warmup", "0", "--workload", "small", "--n", "100",
                            "--m", "50", "--dry-launch"]))
-    assert out["n_gpus"] == 3 and out["config"]["backend"] == "_NoComputeBackend"
+    assert out["n_gpus"] == 3 and out["config"]["search_backend"] == "_NoComputeBackend"
+    assert out["config"]["backend"] == "gloo" and out["config"]["world"] == 3 and len(out["config"]["devices"]) == 3
 
 
 def test_world_size_mismatch_fails_loudly():
@@ -79,3 +80,57 @@ def test_single_rank_without_gpu_fails_loudly_not_silently_on_cpu():
         return
     p = _run(["--gpus", "1", "--steps", "1", "--workload", "small"])
     assert p.returncode != 0 and "{" not in p.stdout
+
+
+def test_cpu_baseline_uses_the_host_cores_under_torchruns_omp_default():
+    """``torch.distributed.run`` gives each of several workers ``OMP_NUM_THREADS=1`` when the variable
+    is unset; the CPU baseline must still run on, and report, the cores of the host."""
+    code = (
+        "import os, sys, json, numpy as np, torch\n"
+        f"sys.path.insert(0, {str(ROOT)!r})\n"
+        "import bench\n"
+        "from oracle import oracle\n"
+        "U, V, *_ = bench.make_latents('small', 600, 700)\n"
+        "idx, d2 = oracle.knn_dist2(U, V, 30)\n"
+        "st = type('S', (), {'idx': torch.from_numpy(idx), 'dist2': torch.from_numpy(d2)})()\n"
+        "cores = bench.host_cores()\n"
+        "cpu, parity = bench.cpu_baseline_and_parity(U, V, 30, st, 200, cores)\n"
+        "print(json.dumps({'cores': cpu['cores'], 'affinity': len(os.sched_getaffinity(0)),\n"
+        "                  'omp_threads': oracle.host_threads(), 'bad': parity['rows_with_index_mismatch'],\n"
+        "                  'bits': parity['dist2_bit_identical']}))\n")
+    env = {k: v for k, v in os.environ.items()}
+    env["OMP_NUM_THREADS"] = "1"
+    p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    out = _json_line(p)
+    assert out["cores"] == out["affinity"] == out["omp_threads"]
+    assert out["bad"] == 0 and out["bits"] is True
+    # an operator's explicit share (the GPU boxes export 16 on machines whose mask shows every core) bounds it
+    env["OMP_NUM_THREADS"] = "2"
+    p = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); import bench; print('{\"c\": %%d}' %% bench.host_cores())" % str(ROOT)],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert _json_line(p)["c"] == min(2, len(os.sched_getaffinity(0)))
+
+
+def test_stored_traffic_is_found_per_shard_size(tmp_path, monkeypatch):
+    """A rank's launch of the sharded run (n_local rows of the workload against all references) finds
+    the counter profile taken at that shard size; other sizes, kernels or sources find none."""
+    sys.path.insert(0, str(ROOT))
+    import bench
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    kern = "fused_knn_kernel<25, 12, 320, 64, true, false>"
+    for n_local, nbytes in ((1_000_000, 111), (125_000, 222)):
+        (prof / f"x{n_local}_hbm_traffic.json").write_text(json.dumps(
+            {"workload": "c3", "n_local": n_local, "kernel": "scmiac::" + kern,
+             "source_sha256": bench.kernel_source_hash(), "hbm_bytes_per_launch": nbytes}))
+    (prof / "stale_hbm_traffic.json").write_text(json.dumps(
+        {"workload": "c3", "n_local": 250_000, "kernel": "scmiac::" + kern, "source_sha256": "0", "hbm_bytes_per_launch": 5}))
+    real_hash = bench.kernel_source_hash()
+    monkeypatch.setattr(bench, "ROOT", tmp_path)
+    monkeypatch.setattr(bench, "kernel_source_hash", lambda: real_hash)
+    assert bench.stored_traffic("c3", 1_000_000, 1_000_000, kern)[0] == 111
+    assert bench.stored_traffic("c3", 125_000, 1_000_000, kern)[0] == 222
+    assert bench.stored_traffic("c3", 250_000, 1_000_000, kern) == (None, "kernel sources changed since the stored profile stale_hbm_traffic.json was taken")
+    assert bench.stored_traffic("c3", 500_000, 1_000_000, kern)[0] is None
+    assert bench.stored_traffic("c3", 125_000, 1_000_000, "other")[0] is None
+    assert bench.stored_traffic(None, 125_000, 1_000_000, kern)[0] is None
