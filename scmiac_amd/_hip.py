@@ -270,13 +270,13 @@ def anchor_filter(pairs, n_pairs, raw_score, p_lo, p_hi, codes1, codes2, *, thre
 
 def knn_diag(n, m, d, k, splits=0, device=None):
     """Per-wave counters of the last fused kernel (needs ``set_tuning(diag=True)`` at search time):
-    int64 array [waves, 12]."""
+    int64 array [waves, 16]."""
     off, nbytes, waves = ctypes.c_size_t(0), ctypes.c_size_t(0), ctypes.c_int(0)
     _check(load_library().scmiac_knn_diag_region(n, m, d, k, splits, ctypes.byref(off), ctypes.byref(nbytes),
                                                  ctypes.byref(waves)))
     device = device or torch.device("cuda", torch.cuda.current_device())
     ws = _ws_cache[device]
-    return ws[off.value:off.value + nbytes.value].view(torch.int64).view(waves.value, 12).cpu().numpy()
+    return ws[off.value:off.value + nbytes.value].view(torch.int64).view(waves.value, 16).cpu().numpy()
 
 
 def knn_grid_plan(n, m, d, k, splits=0):

@@ -93,7 +93,7 @@ static KnnWs knn_carve(void* ws, long long n, long long m, int d, const KnnGeome
     }
     w.diag = reinterpret_cast<unsigned long long*>(p + off);
     w.diag_offset = off;
-    w.diag_bytes = sizeof(unsigned long long) * 12 * (size_t)g.blocks * g.nw;
+    w.diag_bytes = sizeof(unsigned long long) * 16 * (size_t)g.blocks * g.nw;
     off += up256(w.diag_bytes);
     w.total = off;
     return w;

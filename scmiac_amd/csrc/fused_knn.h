@@ -115,7 +115,7 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
     const float* __restrict__ tau0,   // [n_pad] threshold to start from, or NULL
     float* __restrict__ tau_out,      // [shortlists] threshold each shortlist ended with
     PruneArgs prune,                  // pruning experiment (diagnostic instantiation, tuning bit 64)
-    u64* __restrict__ diag_out /* per wave 8 counters (DIAG_ instantiations only) */) {
+    u64* __restrict__ diag_out /* per wave 16 counters (DIAG_ instantiations only) */) {
     u64* const diag = DIAG_ ? diag_out : nullptr;  // compile-time NULL in the product kernel (may be NULL in the other too)
 #ifndef SCMIAC_ABL
 #define SCMIAC_ABL 0  // experiment builds (-DSCMIAC_ABL=bits) bake an ablation into the product kernel
@@ -246,7 +246,7 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
 
 
     u64 dg_slow = 0, dg_flush = 0, dg_nslow = 0, dg_nflush = 0, dg_npush = 0, dg_iters = 0;
-    u64 dg_seg1 = 0, dg_seg2 = 0, dg_ngen = 0;
+    u64 dg_seg1 = 0, dg_seg2 = 0, dg_ngen = 0, dg_tseed = 0, dg_thome = 0, dg_tloop = 0;
     const u64 dg_t0 = diag ? (u64)clock64() : 0;
 
     // merge every query of this wave that has a full buffer (only_full) or any pending
@@ -441,6 +441,8 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
         }
     }
 
+    if (diag) dg_tseed = (u64)clock64() - dg_t0;
+
     // Pruning experiment.  The partition's pivots give, for every cell c of the reference image,
     // a lower bound of the distance from a query to anything in it: dist(q, p_c) - rho_c (rho_c
     // the largest distance of the cell's rows to their pivot).  At least kt rows score no more
@@ -563,6 +565,7 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         for (int t = 0; t < T_loop; ++t) {
+            if (diag && t == oN) dg_thome = (u64)clock64() - dg_t0;
             if (DIAG_ && pruning && t == replan_at) plan_rest();
             if (do_stage && t + 1 < T_loop) SCMIAC_STAGE(stage_row(t + 1), (t + 1) & 1);
             const float* tb = tile + (do_stage ? (t & 1) : 0) * RT * LS;
@@ -578,6 +581,7 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
             if (do_sync) __syncthreads();
         }
     }
+    if (diag) { dg_tloop = (u64)clock64() - dg_t0; if (oN >= T_loop) dg_thome = dg_tloop; }
     if (T_loop > 0) {  // the last subtile is still untested
         float mn_ = accs[1][0];
 #pragma unroll
@@ -588,10 +592,11 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
     // what the refine pass may assume of every reference this block streamed and did not list
     if (hh == 0) tau_out[list_row + j] = tau;
     if (diag && lane == 0) {
-        u64* o = diag + ((long long)blockIdx.x * NW + wave) * 12;
+        u64* o = diag + ((long long)blockIdx.x * NW + wave) * 16;
         o[0] = (u64)clock64() - dg_t0; o[1] = dg_slow; o[2] = dg_flush; o[3] = dg_nslow;
         o[4] = dg_nflush; o[5] = dg_npush; o[6] = dg_iters; o[7] = dg_seg1;
-        o[8] = dg_seg2; o[9] = dg_ngen; o[10] = 0; o[11] = 0;
+        o[8] = dg_seg2; o[9] = dg_ngen; o[10] = dg_tseed; o[11] = dg_thome;
+        o[12] = dg_tloop; o[13] = (u64)T_loop; o[14] = (u64)oN; o[15] = (u64)SN;
     }
 }
 
