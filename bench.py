@@ -470,29 +470,38 @@ def cpu_baseline_and_parity(Q, R, k, st, rows_arg, cores):
 
 
 def pruned_search(q_dev, r_dev, k, dense):
-    """The same table with the pivot-pruning experiment switched on (tuning bit 64: farthest-point
-    pivots, and every block streams only the cells within reach of its queries).  Exact -- compared
-    here with the dense search's table bit for bit -- but not the dense contraction the headline
-    and the roofline are about: reported next to them, never as them.  None where the partition
-    does not apply."""
-    if q_dev.shape[1] > 64 or r_dev.shape[0] < 16384 or q_dev.shape[0] < 2048:
+    """The same table with the pruned search (``mode="pruned"``: farthest-point pivots, and every
+    block streams only the cells within reach of its queries).  Exact -- compared here with the
+    dense search's table bit for bit -- but not the dense contraction the headline and the roofline
+    are about: reported next to them, never as them.  None where this shape does not prune."""
+    n, m, d = q_dev.shape[0], r_dev.shape[0], q_dev.shape[1]
+    if not _hip.knn_grid_plan(n, m, d, k, mode="pruned")["prunes"]:
         return None
-    try:
-        _hip.set_tuning(ablate=64)
-        _hip.knn_search(q_dev, r_dev, k)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        reps = 3
-        for _ in range(reps):
-            st = _hip.knn_search(q_dev, r_dev, k)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / reps
-    finally:
-        _hip.set_tuning()
-    return {"ms_per_table": round(dt * 1e3, 3), "cells_per_s": round(q_dev.shape[0] / dt, 1),
+    _hip.knn_search(q_dev, r_dev, k, mode="pruned")
+    torch.cuda.synchronize()
+    _hip.set_timing(True)
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        st = _hip.knn_search(q_dev, r_dev, k, mode="pruned")
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    fused_ms, launches = _hip.fused_ms()
+    _hip.set_timing(False)
+    kept, dense_stages = _hip.knn_prune_stats(n, m, d, k)
+    frac = kept / max(dense_stages, 1)
+    kernel_ms = fused_ms / max(launches, 1)
+    # the contraction the kernel still performed: kept share of 2 N M d, over the kernel's time
+    streamed_tflops = 2.0 * n * m * d * frac / (kernel_ms * 1e-3) / 1e12
+    return {"ms_per_table": round(dt * 1e3, 3), "cells_per_s": round(n / dt, 1),
+            "kernel": _hip.knn_kernel_name(n, m, d, k, mode="pruned"), "kernel_ms": round(kernel_ms, 3),
+            "cells": _hip.knn_grid_plan(n, m, d, k, mode="pruned")["cells"],
+            "kept_stage_fraction": round(frac, 4),
+            "mfma_frac_on_streamed_stages": round(streamed_tflops / FP32_MFMA_PEAK_TFLOPS, 4),
             "identical_to_dense_search": bool(torch.equal(st.idx, dense.idx) and torch.equal(st.dist2, dense.dist2)),
-            "note": "experimental, opt-in (scmiac_knn_set_tuning): exact pruning by the partition's pivots; "
-                    "skips most of the dense contraction on clustered data, so it has no MFMA roofline"}
+            "note": "scmiac_knn_search(mode = SCMIAC_KNN_PRUNED): exact pruning by pivot cells; skips most of the dense "
+                    "contraction on clustered data, so it has no roofline of its own (kernel_ms includes the blocks' "
+                    "planning; ms_per_table the choice of pivots and the partition)"}
 
 
 def full_search(U, V, l1, l2, k, dev, rare=0, cpu=None):

@@ -42,12 +42,34 @@ SCMIAC_API int scmiac_version(void);
 SCMIAC_API const char *scmiac_last_error(void);
 
 /*
+ * How scmiac_knn_search goes through the reference rows (its `mode` argument).  Both give the
+ * same, exact table.
+ *   SCMIAC_KNN_DENSE   every query block streams every reference row: the dense contraction.
+ *   SCMIAC_KNN_PRUNED  both sets are grouped into cells round pivots taken from the reference rows
+ *                      (farthest-point traversal of a sample), and a query block streams only the
+ *                      cells that can hold a neighbour of one of its queries: those whose pivot
+ *                      distance minus cell radius lies within the queries' reach (triangle
+ *                      inequality, with the rounding-error slack of the search's own certificate).
+ *                      Many times faster on clustered data (latent embeddings of cell atlases);
+ *                      on data without structure every cell stays within reach and the search
+ *                      costs what the dense one costs plus the choice of pivots.  Available up to
+ *                      64 features and from 16 384 reference / 2 048 query rows on; other shapes
+ *                      run dense.  No counterpart in the reference (its index, pynndescent, prunes
+ *                      approximately; this is exact).
+ */
+#define SCMIAC_KNN_DENSE 0
+#define SCMIAC_KNN_PRUNED 1
+
+/*
  * Bytes of device scratch scmiac_knn_search needs for an (n x d) query block
  * against an (m x d) reference block.  `splits` = 0 lets the library choose how
  * many reference chunks to search independently (more chunks fill the GPU when n
- * is small); pass the same value to scmiac_knn_search.
+ * is small); pass the same `splits` and `mode` to scmiac_knn_search.
+ * (Planning reads the tuning knobs once per call and asks the HIP runtime, once per device and
+ * kernel variant, how many blocks the current device runs at once -- the first planning call of a
+ * process with a GPU therefore initialises the runtime; without a device it assumes an MI355X.)
  */
-SCMIAC_API int scmiac_knn_workspace_size(int64_t n, int64_t m, int d, int k, int splits, size_t *bytes);
+SCMIAC_API int scmiac_knn_workspace_size(int64_t n, int64_t m, int d, int k, int splits, int mode, size_t *bytes);
 
 /*
  * Exact k nearest reference rows for every query row -- the arithmetic behind
@@ -78,13 +100,17 @@ SCMIAC_API int scmiac_knn_workspace_size(int64_t n, int64_t m, int d, int k, int
  *                 evaluation before returning, so the result is exact for every
  *                 row (use 0 only when `r` is one block of several; then call
  *                 scmiac_knn_exact_rows for each block afterwards).
+ *   mode          SCMIAC_KNN_DENSE or SCMIAC_KNN_PRUNED (above); the workspace must have been
+ *                 sized for the same mode.  One call reads the tuning knobs once: its plan, its
+ *                 carve-up of the workspace and its choice of kernel always agree, and a workspace
+ *                 sized under other knobs is refused (SCMIAC_ERR_WORKSPACE) when too small.
  *   1 <= k <= SCMIAC_KNN_MAX_K, 1 <= d <= SCMIAC_KNN_MAX_D, n, m < 2^31.
  *   Inputs must be finite with squared row norms below 1e37 (latent embeddings are
  *   many orders of magnitude inside that).  Rows containing NaN or infinities do not
  *   fault or hang the search, but their results are unspecified.
  */
 SCMIAC_API int scmiac_knn_search(const float *q, int64_t n, const float *r, int64_t m, int d, int k,
-                      int64_t col_offset, int merge, int splits, int32_t *idx, float *dist2,
+                      int64_t col_offset, int merge, int splits, int mode, int32_t *idx, float *dist2,
                       float *dist, double *lower_bound, int32_t *uncertified_rows,
                       int32_t *n_uncertified, int exact_fallback, void *workspace,
                       size_t workspace_bytes, void *stream);
@@ -179,10 +205,8 @@ SCMIAC_API int scmiac_anchor_filter(const int64_t *pairs, const int64_t *n_pairs
  *   no_tail        1: do not split the last round's query blocks further
  *   ablate         ablation bits honoured by the diagnostic kernel instantiation only
  *                  (1 no selection, 2 no staging, 4 no barrier, 8 empty candidate path,
- *                  16 candidate arithmetic only): results are then NOT a k-NN table.
- *                  Bit 64 is no ablation but an experiment: exact pruning by the partition's
- *                  pivots -- a block streams only the cells within reach of its queries; the
- *                  tables stay identical, the dense contraction is no longer performed
+ *                  16 candidate arithmetic only, 32 no seed pass): results are then NOT a k-NN
+ *                  table (bit 32 excepted)
  *   diag           1: per-wave counters, see scmiac_knn_diag_region
  *   nw, rt, pcap, gp  kernel variant (waves per block, rows per LDS stage, pending
  *                  candidates per query, 1 = pending buffers in global memory); all zero
@@ -193,8 +217,9 @@ SCMIAC_API int scmiac_anchor_filter(const int64_t *pairs, const int64_t *n_pairs
  *                  both sets by nearest pivot first (same result, A/B timing aid)
  *   home_rows, seed_rows, cell_rows  > 0: override how many of its queries' home rows a
  *                  block streams first (8192), how many of them the seed pass looks at
- *                  (3072) and the reference rows per pivot cell aimed at (1024)
- * Thread-safe; affects searches planned after the call.
+ *                  (3072) and the reference rows per pivot cell aimed at (1024; the library's
+ *                  own choice stops at 248 cells, an explicit value may ask for up to 2048)
+ * Thread-safe; every later call of the library reads the knobs once, at its start.
  */
 SCMIAC_API int scmiac_knn_set_tuning(int slots, int tail_min_rows, int no_tail, int ablate, int diag, int nw,
                                      int rt, int pcap, int gp, int no_locality, int home_rows, int seed_rows,
@@ -209,26 +234,35 @@ SCMIAC_API int scmiac_knn_set_tuning(int slots, int tail_min_rows, int no_tail, 
  *    cycles up to the duplicate check, cycles of the one-candidate-per-lane store,
  *    entries that took the general path, 0, 0}.
  */
-SCMIAC_API int scmiac_knn_diag_region(int64_t n, int64_t m, int d, int k, int splits, size_t *offset,
+SCMIAC_API int scmiac_knn_diag_region(int64_t n, int64_t m, int d, int k, int splits, int mode, size_t *offset,
                                       size_t *bytes, int *waves);
 
 /*
+ * Where a pruned search (SCMIAC_KNN_PRUNED) of this shape leaves its two uint64 counters in the
+ * workspace: {stages of reference rows its blocks streamed, stages the dense search would have
+ * streamed}; their ratio is the share of the dense contraction that was still performed.
+ * SCMIAC_ERR_ARG when a search of this shape does not prune.  No counterpart in the reference.
+ */
+SCMIAC_API int scmiac_knn_prune_stats_offset(int64_t n, int64_t m, int d, int k, int splits, size_t *offset);
+
+/*
  * How scmiac_knn_search would lay its fused kernel's grid out for this problem (no
- * counterpart in the reference; no GPU work).  plan[8] (host memory):
+ * counterpart in the reference; no GPU work).  plan[10] (host memory):
  *   {query blocks, queries per block, S, rows per chunk, main query blocks,
- *    St, rows per tail chunk, grid blocks}
+ *    St, rows per tail chunk, grid blocks, pivot cells (0: no partition), 1 if the search prunes}
  * Query blocks below "main query blocks" are searched in S reference chunks each; the
  * rest -- what would be a partly filled last round of the grid -- in St chunks each.
  */
-SCMIAC_API int scmiac_knn_grid_plan(int64_t n, int64_t m, int d, int k, int splits, int64_t *plan);
+SCMIAC_API int scmiac_knn_grid_plan(int64_t n, int64_t m, int d, int k, int splits, int mode, int64_t *plan);
 
 /*
  * Name of the fused kernel instantiation scmiac_knn_search would launch for this problem,
  * as a profiler prints it without the namespace, e.g.
- * "fused_knn_kernel<25, 12, 320, 64, true, false>" (no counterpart in the reference; no GPU
+ * "fused_knn_kernel<25, 12, 320, 64, true, 0>" (the last parameter: 0 dense product kernel,
+ * 2 pruned product kernel, 1 diagnostic instantiation; no counterpart in the reference; no GPU
  * work).  Lets a measurement say which compiled variant it timed.
  */
-SCMIAC_API int scmiac_knn_kernel_name(int64_t n, int64_t m, int d, int k, int splits, char *buf,
+SCMIAC_API int scmiac_knn_kernel_name(int64_t n, int64_t m, int d, int k, int splits, int mode, char *buf,
                                       size_t buf_bytes);
 
 /*

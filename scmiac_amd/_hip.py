@@ -17,6 +17,7 @@ LIB_PATH = Path(os.environ.get("SCMIAC_HIP_LIB", _HERE / "csrc" / "libscmiac_hip
 
 KNN_MAX_K = 64
 KNN_MAX_D = 256
+KNN_MODES = {"dense": 0, "pruned": 1}  # SCMIAC_KNN_DENSE / SCMIAC_KNN_PRUNED
 
 _lib = None
 
@@ -26,8 +27,8 @@ _vp, _i64, _i32, _sz, _dbl = _c.c_void_p, _c.c_int64, _c.c_int, _c.c_size_t, _c.
 _SIGNATURES = {
     "scmiac_version": ([], _c.c_int),
     "scmiac_last_error": ([], _c.c_char_p),
-    "scmiac_knn_workspace_size": ([_i64, _i64, _i32, _i32, _i32, _c.POINTER(_sz)], _c.c_int),
-    "scmiac_knn_search": ([_vp, _i64, _vp, _i64, _i32, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp,
+    "scmiac_knn_workspace_size": ([_i64, _i64, _i32, _i32, _i32, _i32, _c.POINTER(_sz)], _c.c_int),
+    "scmiac_knn_search": ([_vp, _i64, _vp, _i64, _i32, _i32, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp,
                            _vp, _i32, _vp, _sz, _vp], _c.c_int),
     "scmiac_knn_exact_rows": ([_vp, _i64, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
                               _c.c_int),
@@ -38,10 +39,11 @@ _SIGNATURES = {
                          _c.c_int),
     "scmiac_anchor_filter": ([_vp, _vp, _i64, _vp, _dbl, _dbl, _dbl, _vp, _i64, _vp, _i64, _i32, _vp, _vp,
                               _vp, _vp, _vp, _vp, _vp, _sz, _vp], _c.c_int),
-    "scmiac_knn_diag_region": ([_i64, _i64, _i32, _i32, _i32, _c.POINTER(_sz), _c.POINTER(_sz),
+    "scmiac_knn_diag_region": ([_i64, _i64, _i32, _i32, _i32, _i32, _c.POINTER(_sz), _c.POINTER(_sz),
                                 _c.POINTER(_c.c_int)], _c.c_int),
-    "scmiac_knn_grid_plan": ([_i64, _i64, _i32, _i32, _i32, _c.POINTER(_i64)], _c.c_int),
-    "scmiac_knn_kernel_name": ([_i64, _i64, _i32, _i32, _i32, _c.c_char_p, _sz], _c.c_int),
+    "scmiac_knn_prune_stats_offset": ([_i64, _i64, _i32, _i32, _i32, _c.POINTER(_sz)], _c.c_int),
+    "scmiac_knn_grid_plan": ([_i64, _i64, _i32, _i32, _i32, _i32, _c.POINTER(_i64)], _c.c_int),
+    "scmiac_knn_kernel_name": ([_i64, _i64, _i32, _i32, _i32, _i32, _c.c_char_p, _sz], _c.c_int),
     "scmiac_lu_row_perm": ([_vp, _i32, _i64, _vp, _vp], _c.c_int),
     "scmiac_knn_set_timing": ([_i32], _c.c_int),
     "scmiac_knn_set_tuning": ([_i32] * 13, _c.c_int),
@@ -147,13 +149,29 @@ def _workspace(nbytes, device):
     return ws
 
 
-def knn_search(q, r, k, *, col_offset=0, state=None, splits=0, exact_fallback=True):
+_default_mode = "dense"
+
+
+def set_default_mode(mode):
+    """``"dense"`` or ``"pruned"``: how searches that do not say so themselves go through the
+    reference rows (see ``SCMIAC_KNN_PRUNED`` in the header; both give the same, exact tables).
+    Returns the previous setting."""
+    global _default_mode
+    if mode not in KNN_MODES:
+        raise ValueError(f"mode must be one of {sorted(KNN_MODES)}")
+    previous, _default_mode = _default_mode, mode
+    return previous
+
+
+def knn_search(q, r, k, *, col_offset=0, state=None, splits=0, exact_fallback=True, mode=None):
     """Exact k-NN of the rows of ``q`` among the rows of ``r`` (device tensors).
 
     Returns a :class:`KnnState`; pass it back as ``state`` with another
     reference block (and that block's ``col_offset``) to extend the search.
+    ``mode``: ``"dense"`` / ``"pruned"`` (None: :func:`set_default_mode`'s, initially dense).
     """
     lib = require_gpu()
+    mode_i = KNN_MODES[mode or _default_mode]
     device = q.device if isinstance(q, torch.Tensor) and q.is_cuda else torch.device("cuda", torch.cuda.current_device())
     q = _dev_f32(q, device)
     r = _dev_f32(r, device)
@@ -167,10 +185,10 @@ def knn_search(q, r, k, *, col_offset=0, state=None, splits=0, exact_fallback=Tr
     elif state.idx.shape != (n, k):
         raise ValueError("state does not match (n, k)")
     nbytes = ctypes.c_size_t(0)
-    _check(lib.scmiac_knn_workspace_size(n, m, d, k, splits, ctypes.byref(nbytes)))
+    _check(lib.scmiac_knn_workspace_size(n, m, d, k, splits, mode_i, ctypes.byref(nbytes)))
     ws = _workspace(nbytes.value, device)
     with torch.cuda.device(device):
-        _check(lib.scmiac_knn_search(_ptr(q), n, _ptr(r), m, d, k, col_offset, merge, splits, _ptr(state.idx),
+        _check(lib.scmiac_knn_search(_ptr(q), n, _ptr(r), m, d, k, col_offset, merge, splits, mode_i, _ptr(state.idx),
                                      _ptr(state.dist2), _ptr(state.dist), _ptr(state.lower_bound),
                                      _ptr(state.uncertified_rows), _ptr(state.n_uncertified),
                                      1 if exact_fallback else 0, _ptr(ws), ws.numel(), _stream()))
@@ -268,30 +286,40 @@ def anchor_filter(pairs, n_pairs, raw_score, p_lo, p_hi, codes1, codes2, *, thre
     return out_pairs, out_score, out_same, out_index, counts, all_score
 
 
-def knn_diag(n, m, d, k, splits=0, device=None):
+def knn_diag(n, m, d, k, splits=0, device=None, mode=None):
     """Per-wave counters of the last fused kernel (needs ``set_tuning(diag=True)`` at search time):
     int64 array [waves, 16]."""
     off, nbytes, waves = ctypes.c_size_t(0), ctypes.c_size_t(0), ctypes.c_int(0)
-    _check(load_library().scmiac_knn_diag_region(n, m, d, k, splits, ctypes.byref(off), ctypes.byref(nbytes),
-                                                 ctypes.byref(waves)))
+    _check(load_library().scmiac_knn_diag_region(n, m, d, k, splits, KNN_MODES[mode or _default_mode],
+                                                 ctypes.byref(off), ctypes.byref(nbytes), ctypes.byref(waves)))
     device = device or torch.device("cuda", torch.cuda.current_device())
     ws = _ws_cache[device]
     return ws[off.value:off.value + nbytes.value].view(torch.int64).view(waves.value, 16).cpu().numpy()
 
 
-def knn_grid_plan(n, m, d, k, splits=0):
-    """Grid layout of the fused kernel for this problem (needs no GPU)."""
-    plan = (_i64 * 8)()
-    _check(load_library().scmiac_knn_grid_plan(n, m, d, k, splits, plan))
+def knn_prune_stats(n, m, d, k, splits=0, device=None):
+    """``(stages streamed, stages of the dense stream)`` of the last pruned search of this shape on
+    ``device`` (read from the workspace it used)."""
+    off = ctypes.c_size_t(0)
+    _check(load_library().scmiac_knn_prune_stats_offset(n, m, d, k, splits, ctypes.byref(off)))
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    kept, dense = _ws_cache[device][off.value:off.value + 16].view(torch.int64).cpu().tolist()
+    return kept, dense
+
+
+def knn_grid_plan(n, m, d, k, splits=0, mode=None):
+    """Grid layout of the fused kernel for this problem (planning only: no kernel runs)."""
+    plan = (_i64 * 10)()
+    _check(load_library().scmiac_knn_grid_plan(n, m, d, k, splits, KNN_MODES[mode or _default_mode], plan))
     names = ("query_blocks", "queries_per_block", "S", "chunk_rows", "main_query_blocks", "St",
-             "tail_chunk_rows", "grid_blocks")
+             "tail_chunk_rows", "grid_blocks", "cells", "prunes")
     return dict(zip(names, (int(v) for v in plan)))
 
 
-def knn_kernel_name(n, m, d, k, splits=0):
-    """Instantiation of the fused kernel a search of this shape launches (needs no GPU)."""
+def knn_kernel_name(n, m, d, k, splits=0, mode=None):
+    """Instantiation of the fused kernel a search of this shape launches (planning only)."""
     buf = ctypes.create_string_buffer(128)
-    _check(load_library().scmiac_knn_kernel_name(n, m, d, k, splits, buf, len(buf)))
+    _check(load_library().scmiac_knn_kernel_name(n, m, d, k, splits, KNN_MODES[mode or _default_mode], buf, len(buf)))
     return buf.value.decode()
 
 

@@ -44,6 +44,7 @@ struct KnnWs {
     LocalityWs loc;  // pivot partition (all NULL when the geometry has no cells)
     unsigned long long* diag;  // per-wave counters of the fused kernel (diagnostic runs)
     size_t diag_offset, diag_bytes;
+    size_t stats_offset;       // pruned search: {stages streamed, stages of the dense stream} (0: none)
     size_t total;
 };
 static KnnWs knn_carve(void* ws, long long n, long long m, int d, const KnnGeometry& g) {
@@ -70,12 +71,14 @@ static KnnWs knn_carve(void* ws, long long n, long long m, int d, const KnnGeome
     w.tau_out = reinterpret_cast<float*>(take(sizeof(float) * (size_t)g.list_rows));
     w.tau0 = reinterpret_cast<float*>(take(sizeof(float) * (size_t)g.n_pad));
     w.loc = LocalityWs{};
+    w.stats_offset = 0;
     if (g.cells > 0) {
-        const size_t nbq = (size_t)((n + 255) / 256), nbr = (size_t)((m + 255) / 256);
+        const size_t rb = (size_t)knn_cell_block_rows(d);  // rows per block of the partition kernels
+        const size_t nbq = ((size_t)n + rb - 1) / rb, nbr = ((size_t)m + rb - 1) / rb;
         w.loc.pivT = reinterpret_cast<float*>(take(sizeof(float) * (size_t)d * g.cells_pad));
         w.loc.pnorm = reinterpret_cast<float*>(take(sizeof(float) * (size_t)g.cells_pad));
-        w.loc.cell_q = take((size_t)n);
-        w.loc.cell_r = take((size_t)m);
+        w.loc.cell_q = reinterpret_cast<cell_t*>(take(sizeof(cell_t) * (size_t)n));
+        w.loc.cell_r = reinterpret_cast<cell_t*>(take(sizeof(cell_t) * (size_t)m));
         w.loc.hist_q = reinterpret_cast<int*>(take(sizeof(int) * nbq * g.cells));
         w.loc.hist_r = reinterpret_cast<int*>(take(sizeof(int) * nbr * g.cells));
         w.loc.cstart_q = reinterpret_cast<int*>(take(sizeof(int) * 2 * (size_t)(g.cells + 1)));  // starts, then totals
@@ -83,12 +86,17 @@ static KnnWs knn_carve(void* ws, long long n, long long m, int d, const KnnGeome
         w.loc.perm_q = reinterpret_cast<int*>(take(sizeof(int) * (size_t)n));
         w.loc.perm_r = reinterpret_cast<int*>(take(sizeof(int) * (size_t)m));
         w.loc.home = reinterpret_cast<int*>(take(sizeof(int) * 2 * (size_t)g.nqb));
-        if (g.prune) {  // pruning experiment: distances to the pivots, cell radii, per-block stage lists
+        if (g.prune) {  // pruned search: distances to the pivots, cell radii, per-block stage lists, counters
             w.loc.qpd = reinterpret_cast<float*>(take(sizeof(float) * (size_t)g.cells_pad * (size_t)n));
             w.loc.crad = reinterpret_cast<unsigned*>(take(sizeof(unsigned) * (size_t)g.cells_pad));
-            size_t order_bytes = sizeof(unsigned short) * (size_t)g.blocks * (size_t)(g.chunk_rows / g.RT + 1);
+            // a block's list holds at most the stages of its chunk; main and tail blocks differ in that
+            const long long longest = g.chunk_rows > g.tail.chunk_rows ? g.chunk_rows : g.tail.chunk_rows;
+            w.loc.order_stride = (int)(longest / g.RT + 1);
+            size_t order_bytes = sizeof(unsigned short) * (size_t)g.blocks * (size_t)w.loc.order_stride;
             if (order_bytes < sizeof(int) * (size_t)g.cells_pad) order_bytes = sizeof(int) * (size_t)g.cells_pad;
             w.loc.order = reinterpret_cast<unsigned short*>(take(order_bytes));  // (its head first holds the pivots' rows)
+            w.stats_offset = off;
+            w.loc.stats = reinterpret_cast<unsigned long long*>(take(2 * sizeof(unsigned long long)));
         }
     }
     w.diag = reinterpret_cast<unsigned long long*>(p + off);
@@ -97,6 +105,12 @@ static KnnWs knn_carve(void* ws, long long n, long long m, int d, const KnnGeome
     off += up256(w.diag_bytes);
     w.total = off;
     return w;
+}
+
+static int check_knn_mode(int mode) {
+    if (mode != SCMIAC_KNN_DENSE && mode != SCMIAC_KNN_PRUNED)
+        return fail(SCMIAC_ERR_ARG, "mode %d is neither SCMIAC_KNN_DENSE nor SCMIAC_KNN_PRUNED", mode);
+    return SCMIAC_OK;
 }
 
 static int check_knn_args(int64_t n, int64_t m, int d, int k) {
@@ -122,22 +136,24 @@ int scmiac_version(void) { return 1000; }
 
 const char* scmiac_last_error(void) { return g_err; }
 
-int scmiac_knn_workspace_size(int64_t n, int64_t m, int d, int k, int splits, size_t* bytes) {
+int scmiac_knn_workspace_size(int64_t n, int64_t m, int d, int k, int splits, int mode, size_t* bytes) {
     if (!bytes) return fail(SCMIAC_ERR_ARG, "bytes is NULL");
     int rc = check_knn_args(n, m, d, k);
     if (rc) return rc;
-    KnnGeometry g = knn_geometry(n, m, d, k, splits);
+    if ((rc = check_knn_mode(mode))) return rc;
+    KnnGeometry g = knn_geometry(n, m, d, k, splits, mode, knn_get_tuning());
     if (g.D2 < 0) return fail(SCMIAC_ERR_ARG, "unsupported feature dimension %d", d);
     *bytes = knn_carve(nullptr, n, m, d, g).total;
     return SCMIAC_OK;
 }
 
-int scmiac_knn_diag_region(int64_t n, int64_t m, int d, int k, int splits, size_t* offset, size_t* bytes,
+int scmiac_knn_diag_region(int64_t n, int64_t m, int d, int k, int splits, int mode, size_t* offset, size_t* bytes,
                            int* waves) {
     if (!offset || !bytes || !waves) return fail(SCMIAC_ERR_ARG, "NULL output pointer");
     int rc = check_knn_args(n, m, d, k);
     if (rc) return rc;
-    KnnGeometry g = knn_geometry(n, m, d, k, splits);
+    if ((rc = check_knn_mode(mode))) return rc;
+    KnnGeometry g = knn_geometry(n, m, d, k, splits, mode, knn_get_tuning());
     if (g.D2 < 0) return fail(SCMIAC_ERR_ARG, "unsupported feature dimension %d", d);
     KnnWs w = knn_carve(nullptr, n, m, d, g);
     *offset = w.diag_offset;
@@ -146,50 +162,72 @@ int scmiac_knn_diag_region(int64_t n, int64_t m, int d, int k, int splits, size_
     return SCMIAC_OK;
 }
 
-int scmiac_knn_grid_plan(int64_t n, int64_t m, int d, int k, int splits, int64_t* plan) {
-    if (!plan) return fail(SCMIAC_ERR_ARG, "plan is NULL");
+int scmiac_knn_prune_stats_offset(int64_t n, int64_t m, int d, int k, int splits, size_t* offset) {
+    if (!offset) return fail(SCMIAC_ERR_ARG, "offset is NULL");
     int rc = check_knn_args(n, m, d, k);
     if (rc) return rc;
-    KnnGeometry g = knn_geometry(n, m, d, k, splits);
+    KnnGeometry g = knn_geometry(n, m, d, k, splits, SCMIAC_KNN_PRUNED, knn_get_tuning());
     if (g.D2 < 0) return fail(SCMIAC_ERR_ARG, "unsupported feature dimension %d", d);
-    plan[0] = g.nqb; plan[1] = g.qpb; plan[2] = g.S; plan[3] = g.chunk_rows;
-    plan[4] = g.tail.qb0; plan[5] = g.tail.St; plan[6] = g.tail.chunk_rows; plan[7] = g.blocks;
+    if (!g.prune) return fail(SCMIAC_ERR_ARG, "a search of this shape does not prune (it runs dense)");
+    *offset = knn_carve(nullptr, n, m, d, g).stats_offset;
     return SCMIAC_OK;
 }
 
-int scmiac_knn_kernel_name(int64_t n, int64_t m, int d, int k, int splits, char* buf, size_t buf_bytes) {
+int scmiac_knn_grid_plan(int64_t n, int64_t m, int d, int k, int splits, int mode, int64_t* plan) {
+    if (!plan) return fail(SCMIAC_ERR_ARG, "plan is NULL");
+    int rc = check_knn_args(n, m, d, k);
+    if (rc) return rc;
+    if ((rc = check_knn_mode(mode))) return rc;
+    KnnGeometry g = knn_geometry(n, m, d, k, splits, mode, knn_get_tuning());
+    if (g.D2 < 0) return fail(SCMIAC_ERR_ARG, "unsupported feature dimension %d", d);
+    plan[0] = g.nqb; plan[1] = g.qpb; plan[2] = g.S; plan[3] = g.chunk_rows;
+    plan[4] = g.tail.qb0; plan[5] = g.tail.St; plan[6] = g.tail.chunk_rows; plan[7] = g.blocks;
+    plan[8] = g.cells; plan[9] = g.prune;
+    return SCMIAC_OK;
+}
+
+int scmiac_knn_kernel_name(int64_t n, int64_t m, int d, int k, int splits, int mode, char* buf, size_t buf_bytes) {
     if (!buf || buf_bytes == 0) return fail(SCMIAC_ERR_ARG, "buf is NULL or empty");
     int rc = check_knn_args(n, m, d, k);
     if (rc) return rc;
-    KnnGeometry g = knn_geometry(n, m, d, k, splits);
-    if (g.D2 < 0) return fail(SCMIAC_ERR_ARG, "unsupported feature dimension %d", d);
+    if ((rc = check_knn_mode(mode))) return rc;
     const FusedTuning tn = knn_get_tuning();
-    snprintf(buf, buf_bytes, "fused_knn_kernel<%d, %d, %d, %d, %s, %s>", g.D2, g.nw, g.RT, g.pcap,
-             g.gp ? "true" : "false", (tn.diag || tn.ablate) ? "true" : "false");
+    KnnGeometry g = knn_geometry(n, m, d, k, splits, mode, tn);
+    if (g.D2 < 0) return fail(SCMIAC_ERR_ARG, "unsupported feature dimension %d", d);
+    const int kind = (tn.diag || (tn.ablate & 63)) ? 1 : (g.prune ? 2 : 0);
+    snprintf(buf, buf_bytes, "fused_knn_kernel<%d, %d, %d, %d, %s, %d>", g.D2, g.nw, g.RT, g.pcap,
+             g.gp ? "true" : "false", kind);
     return SCMIAC_OK;
 }
 
 int scmiac_knn_search(const float* q, int64_t n, const float* r, int64_t m, int d, int k,
-                      int64_t col_offset, int merge, int splits, int32_t* idx, float* dist2, float* dist,
+                      int64_t col_offset, int merge, int splits, int mode, int32_t* idx, float* dist2, float* dist,
                       double* lower_bound, int32_t* uncertified_rows, int32_t* n_uncertified,
                       int exact_fallback, void* workspace, size_t workspace_bytes, void* stream_) {
     int rc = check_knn_args(n, m, d, k);
     if (rc) return rc;
+    if ((rc = check_knn_mode(mode))) return rc;
     if (col_offset < 0 || col_offset + m >= (1ll << 31)) return fail(SCMIAC_ERR_ARG, "col_offset out of range");
     if (n == 0) return SCMIAC_OK;
     if (!q || !idx || !dist2 || !lower_bound || !uncertified_rows || !n_uncertified || !workspace)
         return fail(SCMIAC_ERR_ARG, "NULL device pointer");
     if (m > 0 && !r) return fail(SCMIAC_ERR_ARG, "NULL reference pointer");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    KnnGeometry g = knn_geometry(n, m, d, k, splits);
+    // one snapshot of the tuning state for the whole call: plan, carve-up and kernel choice agree
+    const FusedTuning tn = knn_get_tuning();
+    KnnGeometry g = knn_geometry(n, m, d, k, splits, mode, tn);
     if (g.D2 < 0) return fail(SCMIAC_ERR_ARG, "unsupported feature dimension %d", d);
     KnnWs w = knn_carve(workspace, n, m, d, g);
     if (w.total > workspace_bytes)
-        return fail(SCMIAC_ERR_WORKSPACE, "workspace holds %zu bytes, %zu needed", workspace_bytes, w.total);
+        return fail(SCMIAC_ERR_WORKSPACE, "workspace holds %zu bytes, %zu needed (sized for another mode, shape or "
+                    "tuning state?)", workspace_bytes, w.total);
 
     HIP_TRY(hipMemsetAsync(w.maxnorm, 0, 256, stream), "memset maxnorm");
     HIP_TRY(hipMemsetAsync(n_uncertified, 0, sizeof(int32_t), stream), "memset n_uncertified");
-    if (g.prune) HIP_TRY(hipMemsetAsync(w.loc.crad, 0, sizeof(unsigned) * (size_t)g.cells_pad, stream), "memset radii");
+    if (g.prune) {
+        HIP_TRY(hipMemsetAsync(w.loc.crad, 0, sizeof(unsigned) * (size_t)g.cells_pad, stream), "memset radii");
+        HIP_TRY(hipMemsetAsync(w.loc.stats, 0, 2 * sizeof(unsigned long long), stream), "memset counters");
+    }
     if (g.cells > 0) HIP_TRY(launch_locality(q, n, r, m, d, g, w.loc, stream), "locality partition");
     HIP_TRY(launch_pack(q, n, d, g, -2.0f, w.qp, g.rowf, nullptr, g.n_pad, w.maxnorm, w.loc.perm_q, stream), "pack queries");
     HIP_TRY(launch_pack(r, m, d, g, 1.0f, w.rp, g.ls, w.rnorm, g.m_pad, w.maxnorm, w.loc.perm_r, stream), "pack references");
@@ -212,9 +250,8 @@ int scmiac_knn_search(const float* q, int64_t n, const float* r, int64_t m, int 
         }
     }
     if (slot >= 0) HIP_TRY(hipEventRecord(g_ev0[slot], stream), "event record");
-    const bool diag = knn_get_tuning().diag != 0;  // diagnostic runs: per-wave cycle counters
-    HIP_TRY(launch_fused(g, w.qp, w.rp, w.rnorm, w.lists, w.pend, n, knn_threshold_rank(k, d), w.loc.home, tau0, w.tau_out,
-                         knn_prune_args(g, w.loc, w.maxnorm, n, d), diag ? w.diag : nullptr, stream),
+    HIP_TRY(launch_fused(g, tn, w.qp, w.rp, w.rnorm, w.lists, w.pend, n, knn_threshold_rank(k, d), w.loc.home, tau0, w.tau_out,
+                         knn_prune_args(g, w.loc, w.maxnorm, n, m, d), tn.diag ? w.diag : nullptr, stream),
             "fused distance + top-k");
     if (slot >= 0) HIP_TRY(hipEventRecord(g_ev1[slot], stream), "event record");
     HIP_TRY(launch_refine(q, w.qp, w.rp, d, n, g, w.lists, k, knn_threshold_rank(k, d), col_offset, merge, w.maxnorm, w.tau_out,
@@ -418,7 +455,7 @@ int scmiac_closer_count_workspace_size(int64_t n, int64_t m, int d, size_t* byte
     if (!bytes) return fail(SCMIAC_ERR_ARG, "bytes is NULL");
     int rc = check_knn_args(n, m, d, 1);
     if (rc) return rc;
-    KnnGeometry g = knn_geometry(n, m, d, 30, 0);
+    KnnGeometry g = knn_geometry(n, m, d, 30, 0, SCMIAC_KNN_DENSE, knn_get_tuning());
     if (g.D2 < 0) return fail(SCMIAC_ERR_ARG, "unsupported feature dimension %d", d);
     *bytes = count_pend_offset_total(g, n, m, d, nullptr);
     return SCMIAC_OK;
@@ -433,7 +470,7 @@ int scmiac_closer_count(const float* q, int64_t n, const float* r, int64_t m, in
     if (m == 0) return fail(SCMIAC_ERR_ARG, "no reference rows");
     if (!q || !r || !counts || !status || !workspace) return fail(SCMIAC_ERR_ARG, "NULL device pointer");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    KnnGeometry g = knn_geometry(n, m, d, 30, 0);
+    KnnGeometry g = knn_geometry(n, m, d, 30, 0, SCMIAC_KNN_DENSE, knn_get_tuning());
     if (g.D2 < 0) return fail(SCMIAC_ERR_ARG, "unsupported feature dimension %d", d);
     KnnWs w0;
     size_t total = count_pend_offset_total(g, n, m, d, &w0);

@@ -99,7 +99,10 @@ __device__ __forceinline__ void sort32_regs(float (&v)[32]) {
     }
 }
 
-template <int D2, int NW_, int RT_, int PCAP_, bool GP_, bool DIAG_>
+// KIND_: 0 the product kernel of the dense search; 2 the product kernel of the pruned search
+// (blocks skip the cells of the reference image out of their queries' reach); 1 the diagnostic
+// instantiation: per-wave counters, ablations, and the pruning code as well.
+template <int D2, int NW_, int RT_, int PCAP_, bool GP_, int KIND_>
 __global__ __launch_bounds__(NW_ * 64, (NW_ >= 8 ? NW_ / 4 : 2))
 // exactly this many waves per SIMD: the LDS allows one block per CU, so registers saved
 // beyond that buy nothing, and the scheduler should not trade LDS-read lookahead for them
@@ -114,13 +117,11 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
     int seed_stages,                  // most home stages the seed pass looks at
     const float* __restrict__ tau0,   // [n_pad] threshold to start from, or NULL
     float* __restrict__ tau_out,      // [shortlists] threshold each shortlist ended with
-    PruneArgs prune,                  // pruning experiment (diagnostic instantiation, tuning bit 64)
-    u64* __restrict__ diag_out /* per wave 16 counters (DIAG_ instantiations only) */) {
-    u64* const diag = DIAG_ ? diag_out : nullptr;  // compile-time NULL in the product kernel (may be NULL in the other too)
-#ifndef SCMIAC_ABL
-#define SCMIAC_ABL 0  // experiment builds (-DSCMIAC_ABL=bits) bake an ablation into the product kernel
-#endif
-    const int ablate = DIAG_ ? ablate_in : SCMIAC_ABL;  // otherwise ablations exist in the diagnostic instantiations only
+    PruneArgs prune,                  // pruned search (KIND_ 1 and 2; qpd == NULL: search everything)
+    u64* __restrict__ diag_out /* per wave 16 counters (diagnostic instantiation only) */) {
+    constexpr bool DIAG_ = KIND_ == 1, PRUNE_ = KIND_ != 0;
+    u64* const diag = DIAG_ ? diag_out : nullptr;  // compile-time NULL in the product kernels (may be NULL in the other too)
+    const int ablate = DIAG_ ? ablate_in : 0;      // ablations exist in the diagnostic instantiation only
     using C = FusedCfg<D2, NW_, RT_, PCAP_, GP_>;
     constexpr int D2P = C::D2P, ROWF = C::ROWF, LS = C::LS, RT = C::RT, NW = C::NW;
     constexpr int PCAP = C::PCAP, NSUB = RT / 32, NB = C::NB;
@@ -156,9 +157,7 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
         // seed passes and home stages read the same reference rows and take about as long, and the
         // 32 blocks then walk the rest of their chunk in step -- out of their XCD's L2.
         int b = (int)blockIdx.x;
-#ifndef SCMIAC_NO_XCD_REMAP
         if ((b | 255) < tail.block0) b = (b & ~255) | ((b & 7) << 5) | ((b & 255) >> 3);
-#endif
         split = b / tail.qb0; qb = b % tail.qb0;  // main region: qb0 query blocks
         r_begin = (long long)split * chunk_rows;
         rows_here = chunk_rows;
@@ -190,16 +189,20 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
     // (each stage then comes out of the L2 for all but the first of them), although their seed
     // passes and home stages differ in length: a block that has spent `shift` stage times on
     // those enters the rest of its chunk `shift` stages in and wraps round at the end.
-    const int SN = (home != nullptr && T > 0) ? (HN < seed_stages ? HN : seed_stages) : 0;  // seed pass stages
+    int SN = (home != nullptr && T > 0) ? (HN < seed_stages ? HN : seed_stages) : 0;  // seed pass stages
+    // (pruned search: the reach test needs a threshold that every query has earned among its own
+    // cell's rows.  A chunk that holds those rows streams them before the test; a block whose chunk
+    // does not -- one of several chunks of a query block -- looks at all of them in its seed pass.)
+    if (PRUNE_ && prune.qpd != nullptr && SN > 0 && !(H0 >= G0 && H0 + HN <= G0 + T)) SN = HN;
     const int rest = T - oN;
     const int shift = rest > 0 ? (SN + oN) % rest : 0;
-    // (pruning experiment: after its seed pass a block may decide to stream only part of the rest
+    // (pruned search: after its seed pass a block may decide to stream only part of the rest
     // of its chunk; the chunk-relative numbers of those stages then stand in `order`)
     const unsigned short* order = nullptr;
     int T_loop = T;
     auto stage_row = [&](int i) __attribute__((always_inline)) {  // first reference row of the i-th stage streamed
         int g;
-        if (DIAG_ && order != nullptr && i >= oN) {
+        if (PRUNE_ && order != nullptr && i >= oN) {
             g = G0 + (int)__hip_atomic_load(order + (i - oN), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else if (i < oN) {
             g = O0 + i;
@@ -443,7 +446,7 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
 
     if (diag) dg_tseed = (u64)clock64() - dg_t0;
 
-    // Pruning experiment.  The partition's pivots give, for every cell c of the reference image,
+    // Pruned search.  The partition's pivots give, for every cell c of the reference image,
     // a lower bound of the distance from a query to anything in it: dist(q, p_c) - rho_c (rho_c
     // the largest distance of the cell's rows to their pivot).  At least kt rows score no more
     // than the query's threshold tau, i.e. lie within reach = sqrt(tau + |q|^2 + E) of it (E the
@@ -462,11 +465,12 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
     int own_lo = 0, own_hi = -1; // chunk-relative stages of the queries' own cells
     unsigned short* my_order = nullptr;
     auto plan_rest = [&]() __attribute__((always_inline)) {  // step 2; every thread of the block calls it
-        if constexpr (DIAG_) {
-            __shared__ float reach_s[NW_ * 32];
-            __shared__ int qrow_s[NW_ * 32];
-            __shared__ unsigned cellmask[8];
-            __shared__ int n_keep;
+        if constexpr (PRUNE_) {
+            constexpr int QPB = NW_ * 32, NT = NW_ * 64;
+            __shared__ float reach_s[QPB];
+            __shared__ int qrow_s[QPB];
+            __shared__ unsigned cellmask[KNN_MAX_CELLS / 32];
+            __shared__ int wave_cnt[NW_];
             float part = 0.0f;
 #pragma unroll
             for (int c = 0; c < D2P; ++c) part = fmaf(0.25f * qf[c], qf[c], part);  // qf holds -2 q
@@ -481,11 +485,10 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
                 reach_s[wave * 32 + j] = reach;
                 qrow_s[wave * 32 + j] = (q0 + j < n) ? prune.perm_q[q0 + j] : -1;
             }
-            if (tid < 8) cellmask[tid] = 0u;
-            __syncthreads();
-            constexpr int QPB = NW_ * 32;
             const int C = prune.cells;
-            for (int idx = tid; idx < C * QPB; idx += NW_ * 64) {
+            for (int w = tid; w < (C + 31) / 32; w += NT) cellmask[w] = 0u;
+            __syncthreads();
+            for (int idx = tid; idx < C * QPB; idx += NT) {
                 const int c = idx / QPB, ql = idx - c * QPB;
                 const int qrow = qrow_s[ql];
                 bool need = false;
@@ -498,63 +501,90 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
                 if (__any(need) && lane == 0) atomicOr(&cellmask[c >> 5], 1u << (c & 31));
             }
             __syncthreads();
-            // the stages of the cells within reach, ascending, without the home stages and the own cells'
-            const int done = T_loop - oN;  // entries of the list already there (step 1)
-            if (tid == 0) {
-                int cnt = done, last = -1;
-                for (int c = 0; c < C; ++c) {
-                    if (!((cellmask[c >> 5] >> (c & 31)) & 1u)) continue;
-                    const long long a = prune.cstart_r[c], b = prune.cstart_r[c + 1];
-                    if (b <= a) continue;
-                    int g0 = (int)(a / RT) - G0, g1 = (int)((b - 1) / RT) - G0;
-                    if (g0 <= last) g0 = last + 1;  // (cells follow each other: a stage can belong to two)
-                    if (g0 < 0) g0 = 0;
-                    if (g1 >= T) g1 = T - 1;
-                    for (int g = g0; g <= g1; ++g) {
-                        if (oN > 0 && g >= O0 - G0 && g < O0 - G0 + oN) continue;
-                        if (g >= own_lo && g <= own_hi) continue;
-                        my_order[cnt++] = (unsigned short)g;
+            // The stages that hold rows of a cell within reach, ascending, without the home stages and
+            // the own cells' (already streamed): every thread looks at one stage per round -- which
+            // cells its rows belong to (the cells lie one after the other in the packed image) -- and
+            // the kept stage numbers are appended in order (ballot ranks within a wave, wave totals
+            // through LDS).
+            int cnt = T_loop - oN;  // entries of the list already there (step 1)
+            for (int g0 = 0; g0 < T; g0 += NT) {
+                const int g = g0 + tid;
+                bool keep = false;
+                if (g < T && !(oN > 0 && g >= O0 - G0 && g < O0 - G0 + oN) && !(g >= own_lo && g <= own_hi)) {
+                    const long long ra = (long long)(G0 + g) * RT, rb = ra + RT;  // rows [ra, rb)
+                    if (ra < prune.m) {
+                        // c1: the cell that holds row ra (last cell starting at or before it);
+                        // c2: the last cell starting before rb
+                        int lo = 0, hi = C;  // invariant: cstart[lo] <= ra < cstart[hi] (cstart[C] = m > ra)
+                        while (hi - lo > 1) {
+                            const int mid = (lo + hi) >> 1;
+                            if ((long long)prune.cstart_r[mid] <= ra) lo = mid; else hi = mid;
+                        }
+                        const int c1 = lo;
+                        int c2 = c1;
+                        while (c2 + 1 < C && (long long)prune.cstart_r[c2 + 1] < rb) ++c2;  // a stage spans few cells
+                        for (int c = c1; c <= c2; ++c) keep = keep || ((cellmask[c >> 5] >> (c & 31)) & 1u);
                     }
-                    if (g1 > last) last = g1;
                 }
-                n_keep = cnt;
+                const u64 bal = __ballot(keep);
+                if (lane == 0) wave_cnt[wave] = __popcll(bal);
+                __syncthreads();
+                int before = 0, total = 0;
+#pragma unroll
+                for (int w = 0; w < NW_; ++w) { const int c = wave_cnt[w]; before += (w < wave) ? c : 0; total += c; }
+                if (keep) my_order[cnt + before + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)g;
+                cnt += total;
+                __syncthreads();
             }
+            // (the list was written with plain stores by many threads and is read back from the L2)
+            __threadfence();
             __syncthreads();
-            T_loop = oN + n_keep;
+            T_loop = oN + cnt;
+            if (tid == 0 && prune.stats != nullptr) {
+                atomicAdd(prune.stats, (u64)T_loop);
+                atomicAdd(prune.stats + 1, (u64)T);
+            }
         }
     };
-    if constexpr (DIAG_) {
-        if ((ablate & 64) && prune.qpd != nullptr && home != nullptr && T > 0 && T < 65535) {
-            __shared__ int n_own, s_lo, s_hi;
+    if constexpr (PRUNE_) {
+        if (prune.qpd != nullptr && home != nullptr && T > 0 && T < prune.order_stride) {
+            constexpr int NT = NW_ * 64;
             my_order = prune.order + (long long)blockIdx.x * prune.order_stride;
-            if (tid == 0) {
-                // the block's queries are consecutive in the packed order, i.e. sorted by cell
-                const long long qa = (long long)qb * (NW_ * 32);
-                long long qz = qa + NW_ * 32 - 1;
-                if (qz >= n) qz = n - 1;
-                int cnt = 0, lo = 0, hi = -1;
-                if (qa < n) {
-                    const int c_lo = prune.cell_q[prune.perm_q[qa]], c_hi = prune.cell_q[prune.perm_q[qz]];
-                    const long long a = prune.cstart_r[c_lo], b = prune.cstart_r[c_hi + 1];
-                    if (b > a) {
-                        lo = (int)(a / RT) - G0;
-                        hi = (int)((b - 1) / RT) - G0;
-                        if (lo < 0) lo = 0;
-                        if (hi >= T) hi = T - 1;
-                        for (int g = lo; g <= hi; ++g) {
-                            if (oN > 0 && g >= O0 - G0 && g < O0 - G0 + oN) continue;
-                            my_order[cnt++] = (unsigned short)g;
+            // step 1: the stages of the queries' own cells (the block's queries are consecutive in
+            // the packed order, i.e. sorted by cell), without the home stages
+            const long long qa = (long long)qb * (NW_ * 32);
+            long long qz = qa + NW_ * 32 - 1;
+            if (qz >= n) qz = n - 1;
+            int n_own = 0;
+            if (qa < n) {
+                const int c_lo = prune.cell_q[prune.perm_q[qa]], c_hi = prune.cell_q[prune.perm_q[qz]];
+                const long long a = prune.cstart_r[c_lo], b = prune.cstart_r[c_hi + 1];
+                if (b > a) {
+                    int lo = (int)(a / RT) - G0, hi = (int)((b - 1) / RT) - G0;
+                    if (lo < 0) lo = 0;
+                    if (hi >= T) hi = T - 1;
+                    if (hi >= lo) {
+                        own_lo = lo; own_hi = hi;
+                        // the home stages inside [lo, hi] are left out: [hl, hr)
+                        int hl = O0 - G0, hr = O0 - G0 + oN;
+                        if (hl < lo) hl = lo;
+                        if (hr > hi + 1) hr = hi + 1;
+                        const int cut = (oN > 0 && hr > hl) ? hr - hl : 0;
+                        n_own = hi - lo + 1 - cut;
+                        for (int i = tid; i < n_own; i += NT) {
+                            int g = lo + i;
+                            if (cut > 0 && g >= hl) g += cut;
+                            my_order[i] = (unsigned short)g;
                         }
                     }
                 }
-                n_own = cnt; s_lo = lo; s_hi = hi;
             }
+            __threadfence();
             __syncthreads();
-            own_lo = s_lo; own_hi = s_hi;
             order = my_order;
             T_loop = oN + n_own;
             pruning = true;
-            if (T_loop == 0) plan_rest();       // nothing of its own in this chunk: decide at once
+            if (n_own == 0) plan_rest();        // nothing of its own left in this chunk: decide at once
             else replan_at = T_loop - 1;        // ... else while the last own stage is being fetched
         }
     }
@@ -566,7 +596,7 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
         __syncthreads();
         for (int t = 0; t < T_loop; ++t) {
             if (diag && t == oN) dg_thome = (u64)clock64() - dg_t0;
-            if (DIAG_ && pruning && t == replan_at) plan_rest();
+            if (PRUNE_ && pruning && t == replan_at) plan_rest();
             if (do_stage && t + 1 < T_loop) SCMIAC_STAGE(stage_row(t + 1), (t + 1) & 1);
             const float* tb = tile + (do_stage ? (t & 1) : 0) * RT * LS;
             const float* nb = tnorm + (do_stage ? (t & 1) : 0) * RT;
@@ -603,18 +633,18 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
 #undef SCMIAC_TEST_PREV
 #undef SCMIAC_SEED_PREV
 
-template <int D2, int NW, int RT, int PC, bool GP, bool DIAG>
+template <int D2, int NW, int RT, int PC, bool GP, int KIND>
 hipError_t launch_fused_t(const float* Qp, const float* Rp, const float* rnorm, u64* lists, uint2* pend_g,
                                  long long n, long long n_pad, int nqb, int S, long long chunk_rows,
                                  const FusedTail& tail, int kt, int ablate, const int* home, int seed_stages,
                                  const float* tau0, float* tau_out, const PruneArgs& prune, u64* diag, hipStream_t stream) {
     using C = FusedCfg<D2, NW, RT, PC, GP>;
     size_t lds = C::lds_bytes();
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_knn_kernel<D2, NW, RT, PC, GP, DIAG>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_knn_kernel<D2, NW, RT, PC, GP, KIND>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     dim3 grid((unsigned)(tail.block0 + (nqb - tail.qb0) * tail.St)), block(NW * 64);
-    hipLaunchKernelGGL((fused_knn_kernel<D2, NW, RT, PC, GP, DIAG>), grid, block, lds, stream, Qp, Rp, rnorm, lists, pend_g, n,
+    hipLaunchKernelGGL((fused_knn_kernel<D2, NW, RT, PC, GP, KIND>), grid, block, lds, stream, Qp, Rp, rnorm, lists, pend_g, n,
                        n_pad, nqb, chunk_rows, tail, kt, ablate, home, seed_stages, tau0, tau_out, prune, diag);
     return hipGetLastError();
 }
@@ -623,7 +653,7 @@ hipError_t launch_fused_t(const float* Qp, const float* Rp, const float* rnorm, 
 // blocks of the fused kernel the GPU runs at once (256 one-block CUs when no device answers)
 template <int D2, int NW, int RT, int PC, bool GP>
 int fused_occupancy_t() {
-    constexpr bool DIAG = false;
+    constexpr int KIND = 0;
     using C = FusedCfg<D2, NW, RT, PC, GP>;
     int dev = 0, cus = 0, per_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
@@ -631,9 +661,9 @@ int fused_occupancy_t() {
         (void)hipGetLastError();
         return 256;
     }
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_knn_kernel<D2, NW, RT, PC, GP, DIAG>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_knn_kernel<D2, NW, RT, PC, GP, KIND>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes());
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_knn_kernel<D2, NW, RT, PC, GP, DIAG>, NW * 64,
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_knn_kernel<D2, NW, RT, PC, GP, KIND>, NW * 64,
                                                      C::lds_bytes()) != hipSuccess || per_cu <= 0) {
         (void)hipGetLastError();
         per_cu = 1;
@@ -641,10 +671,11 @@ int fused_occupancy_t() {
     return cus * per_cu;
 }
 
-// dispatch of one translation unit's variants (VARIANTS_ = its list macro)
+// dispatch of one translation unit's variants (VARIANTS_ = its list macro): the dense product
+// kernel and the diagnostic instantiation
 #define SCMIAC_DEFINE_FUSED_TU(N_, VARIANTS_)                                                                          \
     hipError_t launch_fused_tu##N_(const KnnGeometry& g, const FusedLaunch& a) {                                       \
-        const bool diag_inst = a.diag != nullptr || a.ablate != 0;                                                     \
+        if (a.kind == 2) return hipErrorNotFound; /* pruned product kernels live in a unit of their own */             \
         VARIANTS_(SCMIAC_TU_LAUNCH_CASE)                                                                               \
         return hipErrorNotFound;                                                                                       \
     }                                                                                                                  \
@@ -652,16 +683,31 @@ int fused_occupancy_t() {
         VARIANTS_(SCMIAC_TU_OCC_CASE)                                                                                  \
         return 0;                                                                                                      \
     }
+#define SCMIAC_TU_ARGS_(PRUNE_)                                                                                        \
+    a.Qp, a.Rp, a.rnorm, a.lists, static_cast<uint2*>(a.pend_g), a.n, g.n_pad, g.nqb, g.S, g.chunk_rows, g.tail, a.kt,  \
+        a.ablate, a.home, g.seed_stages, a.tau0, a.tau_out, PRUNE_, a.diag, a.stream
 #define SCMIAC_TU_LAUNCH_CASE(V_, NW_, RT_, PC_, GP_)                                                                  \
     if (g.D2 == V_ && g.nw == NW_ && g.RT == RT_ && g.pcap == PC_ && g.gp == GP_)                                      \
-        return diag_inst ? launch_fused_t<V_, NW_, RT_, PC_, (GP_ != 0), true>(                                        \
-                               a.Qp, a.Rp, a.rnorm, a.lists, static_cast<uint2*>(a.pend_g), a.n, g.n_pad, g.nqb, g.S, g.chunk_rows, g.tail, \
-                               a.kt, a.ablate, a.home, g.seed_stages, a.tau0, a.tau_out, a.prune, a.diag, a.stream)             \
-                         : launch_fused_t<V_, NW_, RT_, PC_, (GP_ != 0), false>(                                       \
-                               a.Qp, a.Rp, a.rnorm, a.lists, static_cast<uint2*>(a.pend_g), a.n, g.n_pad, g.nqb, g.S, g.chunk_rows, g.tail, \
-                               a.kt, 0, a.home, g.seed_stages, a.tau0, a.tau_out, PruneArgs{}, a.diag, a.stream);
+        return a.kind == 1 ? launch_fused_t<V_, NW_, RT_, PC_, (GP_ != 0), 1>(SCMIAC_TU_ARGS_(a.prune))                \
+                           : launch_fused_t<V_, NW_, RT_, PC_, (GP_ != 0), 0>(SCMIAC_TU_ARGS_(PruneArgs{}));
 #define SCMIAC_TU_OCC_CASE(V_, NW_, RT_, PC_, GP_)                                                                     \
     if (g.D2 == V_ && g.nw == NW_ && g.RT == RT_ && g.pcap == PC_ && g.gp == GP_)                                      \
         return fused_occupancy_t<V_, NW_, RT_, PC_, (GP_ != 0)>();
+// ... and the unit of the pruned product kernels
+#define SCMIAC_DEFINE_PRUNED_TU(N_, VARIANTS_)                                                                         \
+    hipError_t launch_fused_tu##N_(const KnnGeometry& g, const FusedLaunch& a) {                                       \
+        if (a.kind != 2) return hipErrorNotFound;                                                                      \
+        VARIANTS_(SCMIAC_TU_PRUNED_CASE)                                                                               \
+        return hipErrorNotFound;                                                                                       \
+    }                                                                                                                  \
+    bool fused_pruned_compiled_tu##N_(const KnnGeometry& g) {                                                          \
+        VARIANTS_(SCMIAC_TU_HAS_CASE)                                                                                  \
+        return false;                                                                                                  \
+    }
+#define SCMIAC_TU_PRUNED_CASE(V_, NW_, RT_, PC_, GP_)                                                                  \
+    if (g.D2 == V_ && g.nw == NW_ && g.RT == RT_ && g.pcap == PC_ && g.gp == GP_)                                      \
+        return launch_fused_t<V_, NW_, RT_, PC_, (GP_ != 0), 2>(SCMIAC_TU_ARGS_(a.prune));
+#define SCMIAC_TU_HAS_CASE(V_, NW_, RT_, PC_, GP_)                                                                     \
+    if (g.D2 == V_ && g.nw == NW_ && g.RT == RT_ && g.pcap == PC_ && g.gp == GP_) return true;
 
 }  // namespace scmiac

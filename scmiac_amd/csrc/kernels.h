@@ -46,15 +46,18 @@ struct KnnGeometry {
     int cells_pad;         // cells rounded up to a multiple of 8
     int home_max;          // most home stages a query block streams ahead of its chunk
     int seed_stages;       // home stages the fused kernel's seed pass looks at
-    int prune;             // 1: experimental exact pruning by the partition's pivots (tuning bit 64)
+    int prune;             // 1: pruned search (SCMIAC_KNN_PRUNED): blocks skip the cells out of their queries' reach
 };
+
+typedef unsigned short cell_t;  // number of a pivot cell (at most KNN_MAX_CELLS of them)
+static constexpr int KNN_MAX_CELLS = 2048;
 
 // device scratch of the locality partition (carved out of the search workspace)
 struct LocalityWs {
     float* pivT;            // [d][cells_pad]
     float* pnorm;           // [cells_pad]
-    unsigned char* cell_q;  // [n]
-    unsigned char* cell_r;  // [m]
+    cell_t* cell_q;         // [n]
+    cell_t* cell_r;         // [m]
     int* hist_q;            // [ceil(n / 256)][cells]
     int* hist_r;            // [ceil(m / 256)][cells]
     int* cstart_q;          // [2 (cells + 1)]: first position of every cell, then scratch for the cell sizes
@@ -62,10 +65,12 @@ struct LocalityWs {
     int* perm_q;            // [n]: packed query position -> caller's row
     int* perm_r;            // [m]: packed reference row -> caller's row
     int* home;              // [nqb][2]
-    // pruning experiment only (NULL otherwise)
+    // pruned search only (NULL otherwise)
     float* qpd;             // [cells_pad][n]: lower bound of dist(query row, pivot)
     unsigned* crad;         // [cells_pad]: float bits, upper bound of max dist(reference row, its pivot)
-    unsigned short* order;  // [grid blocks][stages of a chunk]: the stages a block decided to stream
+    unsigned short* order;  // [grid blocks][order_stride]: the stages a block decided to stream
+    int order_stride;       // entries per block in `order`: the longest chunk's stages + 1
+    unsigned long long* stats;  // [2]: stages streamed by all blocks, stages a dense search would have streamed
 };
 
 // Diagnostic / tuning knobs of the fused kernel's grid plan (all zero = product behaviour).
@@ -73,7 +78,7 @@ struct FusedTuning {
     int slots;          // > 0: pretend the GPU runs this many blocks at once
     int tail_min_rows;  // > 0: shortest reference chunk the planner may choose
     int no_tail;        // 1: never split the last round's query blocks further
-    int ablate;         // ablation bits of the diagnostic kernel instantiation
+    int ablate;         // ablation bits of the diagnostic kernel instantiation (1, 2, 4, 8, 16, 32)
     int diag;           // 1: per-wave cycle counters into the workspace
     int no_locality;    // 1: stream the references in the caller's order (no pivot partition)
     int home_rows;      // > 0: most home rows a query block streams first (default 8192)
@@ -82,6 +87,9 @@ struct FusedTuning {
     int has_variant;    // 1: use (nw, rt, pcap, gp) where that combination is compiled
     int nw, rt, pcap, gp;
 };
+// One snapshot per C-ABI call: everything that call plans, carves and launches derives from it, so
+// a concurrent scmiac_knn_set_tuning cannot pair a geometry planned under one setting with a
+// kernel chosen under another.
 FusedTuning knn_get_tuning();
 bool knn_set_tuning(const FusedTuning& t);  // false: rejected (uncompiled variant, negative value)
 
@@ -95,22 +103,28 @@ inline int knn_threshold_rank(int k, int d) {
     const int margin = d > 64 ? 24 : 6;
     return (k + margin < 64) ? k + margin : 64;
 }
-KnnGeometry knn_geometry(long long n, long long m, int d, int k, int splits);
+// mode: 0 dense search, 1 pruned search (honoured where the pruned kernel is compiled and the
+// locality partition applies; the dense search otherwise)
+KnnGeometry knn_geometry(long long n, long long m, int d, int k, int splits, int mode, const FusedTuning& tn);
+int knn_cell_block_rows(int d);  // rows per block of the partition kernels (their per-block histograms' granularity)
+bool fused_pruned_compiled(const KnnGeometry& g);  // is there a pruned instantiation of this geometry's variant?
 
-// Pruning experiment (diagnostic instantiation, tuning bit 64): what the fused kernel needs to
-// decide, per block, which cells of the reference image can hold a neighbour of its queries.
+// Pruned search: what the fused kernel needs to decide, per block, which cells of the reference
+// image can hold a neighbour of its queries.
 struct PruneArgs {
     const float* qpd;          // NULL: no pruning
     long long n;               // row stride of qpd
     const unsigned* crad;
     const int* cstart_r;       // [cells + 1] first packed row of every cell
     const int* perm_q;         // packed query position -> caller's row
-    const unsigned char* cell_q;  // cell of every query (caller's rows)
+    const cell_t* cell_q;      // cell of every query (caller's rows)
     const unsigned* maxnorm;   // max |r|^2 (float bits)
     float err_coef;            // |score + |q|^2 - T| <= err_coef (|r|^2 + |q|^2)
     int cells;
     unsigned short* order;     // [grid blocks][order_stride]
     int order_stride;
+    long long m;               // reference rows (stages past them hold padding only)
+    unsigned long long* stats; // [2]: stages streamed, stages of the dense stream (atomic adds)
 };
 
 // arguments of one launch of the fused kernel that are not part of the geometry
@@ -122,7 +136,8 @@ struct FusedLaunch {
     void* pend_g;
     long long n;
     int kt;
-    int ablate;
+    int ablate;                // ablation bits (diagnostic instantiation only)
+    int kind;                  // 0 product dense kernel, 1 diagnostic instantiation, 2 product pruned kernel
     const int* home;
     const float* tau0;
     float* tau_out;
@@ -140,6 +155,9 @@ int fused_occupancy_tu0(const KnnGeometry& g);
 int fused_occupancy_tu1(const KnnGeometry& g);
 int fused_occupancy_tu2(const KnnGeometry& g);
 int fused_occupancy_tu3(const KnnGeometry& g);
+// pruned product instantiations (the library's own variants up to 64 features): a unit of their own
+hipError_t launch_fused_tu4(const KnnGeometry& g, const FusedLaunch& a);
+bool fused_pruned_compiled_tu4(const KnnGeometry& g);
 
 hipError_t launch_pack(const float* X, long long n, int d, const KnnGeometry& g, float scale, float* Xp,
                        int ld, float* norms, long long n_pad, unsigned* maxnorm_bits, const int* perm,
@@ -148,9 +166,10 @@ hipError_t launch_locality(const float* Q, long long n, const float* R, long lon
                            const LocalityWs& w, hipStream_t stream);
 hipError_t launch_seed_tau(const float* Q, const int* perm_q, int d, long long n, const KnnGeometry& g, const int* idx,
                            const float* d2, int k, const unsigned* maxnorm_bits, float* tau0, hipStream_t stream);
-// the pruning experiment's kernel arguments (qpd == NULL unless the geometry asks for it)
-PruneArgs knn_prune_args(const KnnGeometry& g, const LocalityWs& loc, const unsigned* maxnorm, long long n, int d);
-hipError_t launch_fused(const KnnGeometry& g, const float* Qp, const float* Rp, const float* rnorm,
+// the pruned search's kernel arguments (qpd == NULL unless the geometry asks for it)
+PruneArgs knn_prune_args(const KnnGeometry& g, const LocalityWs& loc, const unsigned* maxnorm, long long n, long long m,
+                         int d);
+hipError_t launch_fused(const KnnGeometry& g, const FusedTuning& tn, const float* Qp, const float* Rp, const float* rnorm,
                         unsigned long long* lists, void* pend_g, long long n, int kt, const int* home,
                         const float* tau0, float* tau_out, const PruneArgs& prune, unsigned long long* diag, hipStream_t stream);
 hipError_t launch_refine(const float* Q, const float* Qp, const float* Rp, int d, long long n, const KnnGeometry& g,

@@ -103,10 +103,15 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict_
 // makes it fast.  Kernels: pivots -> cell of every row + per-block cell counts -> offsets
 // -> stable scatter into a permutation -> home stages per query block.
 // --------------------------------------------------------------------------------
-static constexpr int CELL_ROWS = 256;     // rows per block of the partition kernels
+static constexpr int CELL_NT = 256;       // threads per block of the assignment kernel
 static constexpr int CELL_TP = 8;         // pivots scored together per thread
+static constexpr int CELL_PT = 64;        // pivots per LDS tile
 
-// Pruning experiment: pivots by farthest-point traversal over a sample of the reference rows (each
+// rows per block of the partition kernels: as many as leave the block's rows (feature-major) and
+// one pivot tile within the LDS
+static int cell_rows_per_block(int d) { return d <= 64 ? 256 : (d <= 128 ? 128 : 64); }
+
+// Pruned search: pivots by farthest-point traversal over a sample of the reference rows (each
 // new pivot is the sample row farthest from all pivots so far), so that every cluster of the data
 // gets pivots of its own and no cell has to take in the rows of a cluster without one: the cells'
 // radii, which the pruning bound subtracts, stay at the size of a cluster.  One block; sample row
@@ -176,45 +181,65 @@ __global__ void pivots_kernel(const float* __restrict__ R, long long m, int d, i
 
 // cell[row] = pivot with the smallest |p|^2 - 2 x.p (lowest pivot number among equals);
 // blockhist[block][c] = rows of this block in cell c.
-__global__ __launch_bounds__(CELL_ROWS) void assign_cells_kernel(const float* __restrict__ X, long long n, int d,
-                                                                 const float* __restrict__ pivT,
-                                                                 const float* __restrict__ pnorm, int C, int Cpad,
-                                                                 unsigned char* __restrict__ cell,
-                                                                 int* __restrict__ blockhist,
-                                                                 float* __restrict__ qpd /* [Cpad][n] or NULL */,
-                                                                 unsigned* __restrict__ crad /* [Cpad] or NULL */) {
+// A block holds RB rows feature-major in LDS for the whole pass and streams the pivots through
+// LDS in tiles of CELL_PT (any number of cells, any d up to 256); the 256 / RB threads of a row
+// share a tile's groups of eight pivots among them and their results meet in LDS at the end.
+template <int RB>
+__global__ __launch_bounds__(CELL_NT) void assign_cells_kernel(const float* __restrict__ X, long long n, int d,
+                                                               const float* __restrict__ pivT,
+                                                               const float* __restrict__ pnorm, int C, int Cpad,
+                                                               cell_t* __restrict__ cell,
+                                                               int* __restrict__ blockhist,
+                                                               float* __restrict__ qpd /* [Cpad][n] or NULL */,
+                                                               unsigned* __restrict__ crad /* [Cpad] or NULL */) {
+    constexpr int PG = CELL_NT / RB;       // threads per row
     extern __shared__ __attribute__((aligned(16))) float csm[];
-    float* pT = csm;                       // [d][Cpad]
-    float* pn = pT + d * Cpad;             // [Cpad]
-    float* xT = pn + Cpad;                 // [d][CELL_ROWS + 1]: feature-major, conflict-free both ways
-    int* hist = reinterpret_cast<int*>(xT + d * (CELL_ROWS + 1));  // [Cpad]
+    float* xT = csm;                       // [d][RB + 1]: feature-major, conflict-free both ways
+    float* pT = xT + ((d * (RB + 1) + 3) & ~3);  // [d][CELL_PT], 16-byte aligned
+    float* pn = pT + d * CELL_PT;          // [CELL_PT]
+    float* best_s = pn + CELL_PT;          // [PG][RB]
+    int* bestc_s = reinterpret_cast<int*>(best_s + PG * RB);  // [PG][RB]
+    int* hist = bestc_s + PG * RB;         // [Cpad]
     const int tid = threadIdx.x;
-    const long long row0 = (long long)blockIdx.x * CELL_ROWS;
-    const int nrows = (int)((n - row0) < CELL_ROWS ? (n - row0) : CELL_ROWS);
-    for (int i = tid; i < d * Cpad; i += CELL_ROWS) pT[i] = pivT[i];
-    for (int i = tid; i < Cpad; i += CELL_ROWS) { pn[i] = pnorm[i]; hist[i] = 0; }
+    const int r = tid % RB, pg = tid / RB;
+    const long long row0 = (long long)blockIdx.x * RB;
+    const int nrows = (int)((n - row0) < RB ? (n - row0) : RB);
+    for (int i = tid; i < Cpad; i += CELL_NT) hist[i] = 0;
     const float* src = X + row0 * d;
-    for (int e = tid; e < nrows * d; e += CELL_ROWS) {
-        const int r = e / d, i = e - r * d;
-        xT[i * (CELL_ROWS + 1) + r] = src[e];
+    for (int e = tid; e < nrows * d; e += CELL_NT) {
+        const int rr = e / d, i = e - rr * d;
+        xT[i * (RB + 1) + rr] = src[e];
+    }
+    for (int e = nrows * d + tid; e < RB * d; e += CELL_NT) {  // rows past the end: zeros, never written out
+        const int rr = e / d, i = e - rr * d;
+        xT[i * (RB + 1) + rr] = 0.0f;
     }
     __syncthreads();
-    if (tid < nrows) {
-        float best = __builtin_inff();
-        int bestc = 0;
-        // (pruning experiment) |x|^2, to turn the scores |p|^2 - 2 x.p into distances with a
-        // rounding-error slack: the float32 chain is off by at most about 8e-6 (|p|^2 + |x|^2)
-        float xn = 0.0f;
-        if (qpd != nullptr || crad != nullptr)
-            for (int i = 0; i < d; ++i) { const float x = xT[i * (CELL_ROWS + 1) + tid]; xn = __fmaf_rn(x, x, xn); }
-        for (int c0 = 0; c0 < Cpad; c0 += CELL_TP) {
+    float best = __builtin_inff();
+    int bestc = 0;
+    // (pruned search) |x|^2, to turn the scores |p|^2 - 2 x.p into distances with a rounding-error
+    // slack: the float32 chain is off by at most about 8e-6 (|p|^2 + |x|^2) up to 64 features, and
+    // in proportion to the number of features beyond
+    float xn = 0.0f;
+    if (qpd != nullptr || crad != nullptr)
+        for (int i = 0; i < d; ++i) { const float x = xT[i * (RB + 1) + r]; xn = __fmaf_rn(x, x, xn); }
+    const float slack_coef = 1.6e-5f * (d > 64 ? (float)d / 64.0f : 1.0f);
+    for (int c0 = 0; c0 < Cpad; c0 += CELL_PT) {
+        if (c0 > 0) __syncthreads();  // everyone is done with the previous tile
+        for (int e = tid; e < d * CELL_PT; e += CELL_NT) {
+            const int i = e / CELL_PT, cc = e - i * CELL_PT;
+            pT[e] = (c0 + cc < Cpad) ? pivT[(long long)i * Cpad + c0 + cc] : 0.0f;
+        }
+        if (tid < CELL_PT) pn[tid] = (c0 + tid < Cpad) ? pnorm[c0 + tid] : __builtin_inff();
+        __syncthreads();
+        for (int g8 = pg * CELL_TP; g8 < CELL_PT && c0 + g8 < Cpad; g8 += PG * CELL_TP) {
             float acc[CELL_TP];
 #pragma unroll
-            for (int u = 0; u < CELL_TP; ++u) acc[u] = pn[c0 + u];
+            for (int u = 0; u < CELL_TP; ++u) acc[u] = pn[g8 + u];
             for (int i = 0; i < d; ++i) {
-                const float x2 = -2.0f * xT[i * (CELL_ROWS + 1) + tid];
-                const float4 pa = *reinterpret_cast<const float4*>(pT + i * Cpad + c0);
-                const float4 pb = *reinterpret_cast<const float4*>(pT + i * Cpad + c0 + 4);
+                const float x2 = -2.0f * xT[i * (RB + 1) + r];
+                const float4 pa = *reinterpret_cast<const float4*>(pT + i * CELL_PT + g8);
+                const float4 pb = *reinterpret_cast<const float4*>(pT + i * CELL_PT + g8 + 4);
                 acc[0] = __fmaf_rn(x2, pa.x, acc[0]); acc[1] = __fmaf_rn(x2, pa.y, acc[1]);
                 acc[2] = __fmaf_rn(x2, pa.z, acc[2]); acc[3] = __fmaf_rn(x2, pa.w, acc[3]);
                 acc[4] = __fmaf_rn(x2, pb.x, acc[4]); acc[5] = __fmaf_rn(x2, pb.y, acc[5]);
@@ -222,27 +247,43 @@ __global__ __launch_bounds__(CELL_ROWS) void assign_cells_kernel(const float* __
             }
 #pragma unroll
             for (int u = 0; u < CELL_TP; ++u)
-                if (acc[u] < best) { best = acc[u]; bestc = c0 + u; }  // NaN rows stay in cell 0
-            if (qpd != nullptr) {
+                if (acc[u] < best) { best = acc[u]; bestc = c0 + g8 + u; }  // NaN rows stay in cell 0
+            if (qpd != nullptr && r < nrows) {
 #pragma unroll
-                for (int u = 0; u < CELL_TP; ++u) {  // a lower bound of the distance to pivot c0 + u
-                    const float slack = 1.6e-5f * (pn[c0 + u] + xn);
+                for (int u = 0; u < CELL_TP; ++u) {  // a lower bound of the distance to pivot c0 + g8 + u
+                    const float slack = slack_coef * (pn[g8 + u] + xn);
                     const float lo2 = acc[u] + xn - slack;
-                    qpd[(long long)(c0 + u) * n + row0 + tid] = lo2 > 0.0f ? sqrtf(lo2) * 0.999999f : 0.0f;
+                    qpd[(long long)(c0 + g8 + u) * n + row0 + r] = lo2 > 0.0f ? sqrtf(lo2) * 0.999999f : 0.0f;
                 }
             }
         }
+    }
+    if (PG > 1) {  // the threads of a row: smallest score, lowest pivot number among equals
+        best_s[pg * RB + r] = best;
+        bestc_s[pg * RB + r] = bestc;
+        __syncthreads();
+        if (pg == 0) {
+#pragma unroll
+            for (int o = 1; o < PG; ++o) {
+                const float ob = best_s[o * RB + r];
+                const int oc = bestc_s[o * RB + r];
+                if (ob < best || (ob == best && oc < bestc)) { best = ob; bestc = oc; }
+            }
+        }
+    }
+    if (pg == 0 && r < nrows) {
         if (bestc >= C) bestc = 0;
         if (crad != nullptr) {  // an upper bound of this row's distance to its own pivot
-            const float hi2 = best + xn + 1.6e-5f * (pn[bestc] + xn);
+            const float pnb = pnorm[bestc];
+            const float hi2 = best + xn + slack_coef * (pnb + xn);
             const float hi = hi2 > 0.0f ? sqrtf(hi2) * 1.000001f : 0.0f;  // (NaN rows: inf, their cell is never pruned)
             atomicMax(crad + bestc, __float_as_uint(hi == hi ? hi : __builtin_inff()));
         }
-        cell[row0 + tid] = (unsigned char)bestc;
+        cell[row0 + r] = (cell_t)bestc;
         atomicAdd(&hist[bestc], 1);
     }
     __syncthreads();
-    for (int i = tid; i < C; i += CELL_ROWS) blockhist[(long long)blockIdx.x * C + i] = hist[i];
+    for (int i = tid; i < C; i += CELL_NT) blockhist[(long long)blockIdx.x * C + i] = hist[i];
 }
 
 // blockhist[b][c] -> rows of cell c in blocks before b (one block per cell scans its column);
@@ -281,15 +322,16 @@ __global__ void cell_starts_kernel(const int* __restrict__ col_total, int C, int
     }
 }
 
-// perm[position] = row: rows ordered by (cell, row number)
-__global__ __launch_bounds__(CELL_ROWS) void cell_scatter_kernel(const unsigned char* __restrict__ cell, long long n,
-                                                                 int C, const int* __restrict__ blockoff,
-                                                                 const int* __restrict__ cell_start,
-                                                                 int* __restrict__ perm) {
-    __shared__ unsigned char cs[CELL_ROWS];
+// perm[position] = row: rows ordered by (cell, row number).  Launched with the assignment
+// kernel's rows per block as block size (the per-block histograms are of those blocks).
+__global__ __launch_bounds__(256) void cell_scatter_kernel(const cell_t* __restrict__ cell, long long n,
+                                                           int C, const int* __restrict__ blockoff,
+                                                           const int* __restrict__ cell_start,
+                                                           int* __restrict__ perm) {
+    __shared__ cell_t cs[256];
     const int tid = threadIdx.x;
-    const long long row = (long long)blockIdx.x * CELL_ROWS + tid;
-    cs[tid] = row < n ? cell[row] : 255;
+    const long long row = (long long)blockIdx.x * blockDim.x + tid;
+    cs[tid] = row < n ? cell[row] : (cell_t)0xffff;
     __syncthreads();
     if (row >= n) return;
     const int mine = cs[tid];
@@ -300,7 +342,7 @@ __global__ __launch_bounds__(CELL_ROWS) void cell_scatter_kernel(const unsigned 
 
 // home[b] = {first stage, number of stages} of the reference rows that share a cell with
 // query block b's queries (at most max_stages of them)
-__global__ void home_stages_kernel(const unsigned char* __restrict__ qcell, const int* __restrict__ perm_q,
+__global__ void home_stages_kernel(const cell_t* __restrict__ qcell, const int* __restrict__ perm_q,
                                    long long n, int qpb, int nqb, const int* __restrict__ rcell_start, int RT,
                                    long long m_pad, int max_stages, int* __restrict__ home) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -652,44 +694,53 @@ static bool fused_variant_compiled(int D2, int nw, int rt, int pcap, int gp) {
 #undef SCMIAC_HAS_CASE
     return false;
 }
+// Blocks of the fused kernel the current device runs at once.  Asked of the HIP runtime once per
+// (device, variant) -- which initialises the runtime on the first planning call of a process with
+// a GPU; 256 (one block on each of an MI355X's compute units) where no device answers.
 static int fused_concurrent_blocks(const KnnGeometry& g) {
-    static int cache[32][2];  // variant -> slots; a handful of variants exist
+    static int cache[64][3];  // (device, variant) -> slots; a handful of variants exist
     static int n_cached = 0;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = -1; }
     std::lock_guard<std::mutex> lock(g_plan_mu);
     const int tag = (((g.D2 * 100 + g.nw) * 1000 + g.RT) * 100 + g.pcap) * 2 + g.gp;
     for (int i = 0; i < n_cached; ++i)
-        if (cache[i][0] == tag) return cache[i][1];
+        if (cache[i][0] == tag && cache[i][2] == dev) return cache[i][1];
     int slots = 256;
-    for (auto occ : {fused_occupancy_tu0, fused_occupancy_tu1, fused_occupancy_tu2, fused_occupancy_tu3}) {
-        const int v = occ(g);
-        if (v > 0) slots = v;  // (0: the variant is not that file's)
-    }
-    if (n_cached < 32) { cache[n_cached][0] = tag; cache[n_cached][1] = slots; ++n_cached; }
+    if (dev >= 0)
+        for (auto occ : {fused_occupancy_tu0, fused_occupancy_tu1, fused_occupancy_tu2, fused_occupancy_tu3}) {
+            const int v = occ(g);
+            if (v > 0) slots = v;  // (0: the variant is not that file's)
+        }
+    if (n_cached < 64) { cache[n_cached][0] = tag; cache[n_cached][1] = slots; cache[n_cached][2] = dev; ++n_cached; }
     return slots;
 }
 
-KnnGeometry knn_geometry(long long n, long long m, int d, int k, int splits) {
+bool fused_pruned_compiled(const KnnGeometry& g) { return fused_pruned_compiled_tu4(g); }
+
+KnnGeometry knn_geometry(long long n, long long m, int d, int k, int splits, int mode, const FusedTuning& tn) {
     KnnGeometry g{};
     g.D2 = knn_pick_d2(d);
     if (g.D2 < 0) return g;
     g.D2P = (g.D2 + 3) & ~3;
     g.rowf = 2 * g.D2P;
     g.ls = g.rowf + (((g.rowf / 4) % 2 == 0) ? 4 : 8);
-    const FusedTuning tn = knn_get_tuning();
     fused_variant(g.D2, tn, &g.nw, &g.RT, &g.pcap, &g.gp);
     // locality partition: worth its passes over both sets once the stream is long enough to have
-    // a candidate-dense start worth cutting; its kernels hold a block's rows and the pivots in LDS
+    // a candidate-dense start worth cutting
     g.cells = 0; g.cells_pad = 0; g.home_max = 0; g.seed_stages = 0;
-    if (!tn.no_locality && d <= 64 && m >= 16384 && n >= 2048) {
+    if (!tn.no_locality && m >= 16384 && n >= 2048) {
         long long c = m / (tn.cell_rows > 0 ? tn.cell_rows : 1024);
-        c = c < 8 ? 8 : (c > 248 ? 248 : c);
+        // (assigning a row costs one distance per cell: the library's own choice stops at 248 cells,
+        // an explicit cell size may ask for up to KNN_MAX_CELLS)
+        const long long cmax = tn.cell_rows > 0 ? KNN_MAX_CELLS : 248;
+        c = c < 8 ? 8 : (c > cmax ? cmax : c);
         g.cells = (int)c;
         g.cells_pad = (g.cells + 7) & ~7;
         // a block streams at most this many home stages first ...
         g.home_max = ((tn.home_rows > 0 ? tn.home_rows : 8192) + g.RT - 1) / g.RT;
         // ... and looks at this many of them for its thresholds
         g.seed_stages = ((tn.seed_rows > 0 ? tn.seed_rows : 3072) + g.RT - 1) / g.RT;
-        g.prune = (tn.ablate & 64) ? 1 : 0;  // experiment: exact pruning by the pivots (diagnostic instantiation)
     }
     g.qpb = g.nw * 32;
     g.n_pad = ((n + g.qpb - 1) / g.qpb) * g.qpb;
@@ -777,6 +828,10 @@ KnnGeometry knn_geometry(long long n, long long m, int d, int k, int splits) {
     }
     g.list_rows = (long long)g.S * g.n_pad + (long long)(t.St - 1) * t.rows;
     g.blocks = t.block0 + (g.nqb - t.qb0) * t.St;
+    // pruned search: where the partition applies, the variant has a pruned instantiation and a
+    // block's stage list fits 16-bit stage numbers; the dense search otherwise
+    const long long longest = g.chunk_rows > t.chunk_rows ? g.chunk_rows : t.chunk_rows;
+    g.prune = (mode == 1 && g.cells > 0 && longest / g.RT < 65535 && fused_pruned_compiled(g)) ? 1 : 0;
     return g;
 }
 
@@ -791,25 +846,42 @@ hipError_t launch_pack(const float* X, long long n, int d, const KnnGeometry& g,
 
 // One side of the locality partition: cell of every row of X (nearest pivot), the permutation
 // that orders the rows by (cell, row number) and the first position of every cell.
-static hipError_t launch_cells(const float* X, long long n, int d, const KnnGeometry& g, const float* pivT,
-                               const float* pnorm, unsigned char* cell, int* blockhist, int* cell_start, int* perm,
-                               float* qpd, unsigned* crad, hipStream_t stream) {
-    const int C = g.cells, Cpad = g.cells_pad;
-    const int nblk = (int)((n + CELL_ROWS - 1) / CELL_ROWS);
-    const size_t lds = sizeof(float) * ((size_t)d * Cpad + Cpad + (size_t)d * (CELL_ROWS + 1)) + sizeof(int) * Cpad;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&assign_cells_kernel),
+template <int RB>
+static hipError_t launch_assign(const float* X, long long n, int d, int C, int Cpad, const float* pivT, const float* pnorm,
+                                cell_t* cell, int* blockhist, float* qpd, unsigned* crad, hipStream_t stream) {
+    constexpr int PG = CELL_NT / RB;
+    const int nblk = (int)((n + RB - 1) / RB);
+    const size_t lds = sizeof(float) * ((size_t)((d * (RB + 1) + 3) & ~3) + (size_t)d * CELL_PT + CELL_PT + (size_t)PG * RB) +
+                       sizeof(int) * ((size_t)PG * RB + Cpad);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&assign_cells_kernel<RB>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(assign_cells_kernel, dim3((unsigned)nblk), dim3(CELL_ROWS), lds, stream, X, n, d, pivT, pnorm, C,
+    hipLaunchKernelGGL(assign_cells_kernel<RB>, dim3((unsigned)nblk), dim3(CELL_NT), lds, stream, X, n, d, pivT, pnorm, C,
                        Cpad, cell, blockhist, qpd, crad);
+    return hipGetLastError();
+}
+
+static hipError_t launch_cells(const float* X, long long n, int d, const KnnGeometry& g, const float* pivT,
+                               const float* pnorm, cell_t* cell, int* blockhist, int* cell_start, int* perm,
+                               float* qpd, unsigned* crad, hipStream_t stream) {
+    const int C = g.cells, Cpad = g.cells_pad;
+    const int rb = cell_rows_per_block(d);
+    const int nblk = (int)((n + rb - 1) / rb);
+    hipError_t e = rb == 256 ? launch_assign<256>(X, n, d, C, Cpad, pivT, pnorm, cell, blockhist, qpd, crad, stream)
+                 : rb == 128 ? launch_assign<128>(X, n, d, C, Cpad, pivT, pnorm, cell, blockhist, qpd, crad, stream)
+                             : launch_assign<64>(X, n, d, C, Cpad, pivT, pnorm, cell, blockhist, qpd, crad, stream);
+    if (e != hipSuccess) return e;
     // (the totals pass through the tail of the start array's own allocation: C + 1 .. 2 C + 1)
     int* col_total = cell_start + C + 1;
     hipLaunchKernelGGL(cell_column_scan_kernel, dim3((unsigned)C), dim3(256), 0, stream, blockhist, nblk, C, col_total);
     hipLaunchKernelGGL(cell_starts_kernel, dim3(1), dim3(64), 0, stream, col_total, C, cell_start);
-    hipLaunchKernelGGL(cell_scatter_kernel, dim3((unsigned)nblk), dim3(CELL_ROWS), 0, stream, cell, n, C, blockhist,
+    hipLaunchKernelGGL(cell_scatter_kernel, dim3((unsigned)nblk), dim3(rb), 0, stream, cell, n, C, blockhist,
                        cell_start, perm);
     return hipGetLastError();
 }
+
+// rows per block of the partition kernels for d features (the per-block histograms' row count)
+int knn_cell_block_rows(int d) { return cell_rows_per_block(d); }
 
 hipError_t launch_locality(const float* Q, long long n, const float* R, long long m, int d, const KnnGeometry& g,
                            const LocalityWs& w, hipStream_t stream) {
@@ -847,30 +919,33 @@ hipError_t launch_seed_tau(const float* Q, const int* perm_q, int d, long long n
     return hipGetLastError();
 }
 
-hipError_t launch_fused(const KnnGeometry& g, const float* Qp, const float* Rp, const float* rnorm,
+hipError_t launch_fused(const KnnGeometry& g, const FusedTuning& tn, const float* Qp, const float* Rp, const float* rnorm,
                         unsigned long long* lists, void* pend_g_, long long n, int kt, const int* home,
                         const float* tau0, float* tau_out, const PruneArgs& prune, unsigned long long* diag,
                         hipStream_t stream) {
     uint2* pend_g = static_cast<uint2*>(pend_g_);
-    // counters (diag) and ablations (tuning bits: 1 no selection, 2 no staging, 4 no barrier,
-    // 8 empty candidate path, 16 candidate arithmetic only) live in a separate instantiation
-    // of the kernel; the product kernel carries neither
-    const int ablate = knn_get_tuning().ablate;
-    const FusedLaunch a{Qp, Rp, rnorm, lists, pend_g, n, kt, ablate, home, tau0, tau_out, prune, diag, stream};
-    for (auto launch : {launch_fused_tu0, launch_fused_tu1, launch_fused_tu2, launch_fused_tu3}) {
+    // Three instantiations of every variant: the product kernel (dense), the pruned product kernel
+    // (library variants up to 64 features) and a diagnostic one that carries per-wave counters,
+    // the ablations (tuning bits: 1 no selection, 2 no staging, 4 no barrier, 8 empty candidate
+    // path, 16 candidate arithmetic only, 32 no seed pass) and the pruning code as well.
+    const int ablate = tn.ablate & 63;
+    const int kind = (diag != nullptr || ablate != 0) ? 1 : (prune.qpd != nullptr ? 2 : 0);
+    const FusedLaunch a{Qp, Rp, rnorm, lists, pend_g, n, kt, ablate, kind, home, tau0, tau_out, prune, diag, stream};
+    for (auto launch : {launch_fused_tu0, launch_fused_tu1, launch_fused_tu2, launch_fused_tu3, launch_fused_tu4}) {
         const hipError_t e = launch(g, a);
-        if (e != hipErrorNotFound) return e;  // hipErrorNotFound: the variant is not that file's
+        if (e != hipErrorNotFound) return e;  // hipErrorNotFound: the variant (of this kind) is not that file's
     }
     return hipErrorInvalidValue;
 }
 
-PruneArgs knn_prune_args(const KnnGeometry& g, const LocalityWs& loc, const unsigned* maxnorm, long long n, int d) {
+PruneArgs knn_prune_args(const KnnGeometry& g, const LocalityWs& loc, const unsigned* maxnorm, long long n, long long m,
+                         int d) {
     PruneArgs a{};
-    if (!g.prune || loc.qpd == nullptr || g.chunk_rows / g.RT >= 65535) return a;
+    if (!g.prune || loc.qpd == nullptr) return a;
     double err_abs_coef, rel_keep;
     knn_error_model(d, g, &err_abs_coef, &rel_keep);
     a = PruneArgs{loc.qpd, n, loc.crad, loc.cstart_r, loc.perm_q, loc.cell_q, maxnorm, (float)(err_abs_coef * 1.001), g.cells,
-                  loc.order, (int)(g.chunk_rows / g.RT + 1)};
+                  loc.order, loc.order_stride, m, loc.stats};
     return a;
 }
 

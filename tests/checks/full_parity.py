@@ -27,12 +27,12 @@ def main():
     ap.add_argument("--slice", type=int, default=20000)
     ap.add_argument("--k", type=int, default=30)
     ap.add_argument("--out", default="")
-    ap.add_argument("--prune", action="store_true", help="the pivot-pruning experiment switched on")
+    ap.add_argument("--prune", action="store_true", help="the pruned search (mode='pruned') instead of the dense one")
     a = ap.parse_args()
     t_start = time.time()
     U, V, _, _, d = bench.make_latents(a.workload)
     if a.prune:
-        _hip.set_tuning(ablate=64)
+        _hip.set_default_mode("pruned")
     q_dev, r_dev = torch.from_numpy(U).cuda(), torch.from_numpy(V).cuda()
     st = _hip.knn_search(q_dev, r_dev, a.k)
     torch.cuda.synchronize()
@@ -40,7 +40,7 @@ def main():
     st = _hip.knn_search(q_dev, r_dev, a.k)
     torch.cuda.synchronize()
     print(f"GPU search: {(time.time() - t0) * 1e3:.1f} ms per table", flush=True)
-    _hip.set_tuning()
+    _hip.set_default_mode("dense")
     idx_g, d2_g = st.idx.cpu().numpy(), st.dist2.cpu().numpy()
     oracle.build()
     n = U.shape[0]

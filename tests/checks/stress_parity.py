@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--max-n", type=int, default=3000)
     ap.add_argument("--max-m", type=int, default=40000)
     ap.add_argument("--locality", action="store_true")
-    ap.add_argument("--prune", action="store_true", help="with --locality: the pivot-pruning experiment switched on")
+    ap.add_argument("--prune", action="store_true", help="with --locality: the pruned search (mode='pruned')")
     a = ap.parse_args()
     if a.locality:
         a.max_n, a.max_m = max(a.max_n, 9000), max(a.max_m, 70000)
@@ -66,8 +66,7 @@ def main():
             q *= 1e3
         qd, rd = torch.from_numpy(q).cuda(), torch.from_numpy(r).cuda()
         idx_o, d2_o = oracle.knn_dist2(q, r, k)
-        if a.prune:
-            knobs["ablate"] = 64
+        _hip.set_default_mode("pruned" if a.prune else "dense")
         _hip.set_tuning(**knobs)
         if blocks == 1:
             st = _hip.knn_search(qd, rd, k, splits=int(rng.choice([0, 0, 3])) if a.locality else 0)

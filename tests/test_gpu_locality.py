@@ -117,26 +117,73 @@ def test_structureless_and_degenerate_inputs():
 
 
 @pytest.mark.parametrize("d,unit", [(50, False), (30, True), (64, True)])
-def test_pivot_pruning_experiment_stays_exact(d, unit, tuning):
-    """Tuning bit 64: farthest-point pivots, and every block streams only the cells within reach
-    of its queries.  Well separated clusters (most cells pruned), overlapping ones, outliers,
-    duplicates, chunks and a tail, and blocks merged one after the other: always the oracle's table."""
+def test_pruned_search_stays_exact(d, unit, tuning):
+    """``mode="pruned"`` (SCMIAC_KNN_PRUNED): farthest-point pivots, and every block streams only the
+    cells within reach of its queries.  Well separated clusters (most cells pruned), overlapping
+    ones, outliers, duplicates, chunks and a tail, more than 255 cells, and blocks merged one after
+    the other: always the oracle's table, and the dense search's."""
     for spread, C in ((1.0, 40), (4.0, 12)):
         Q, _ = _clustered(11, 5000, d, C, spread=spread, unit=unit)
         R, _ = _clustered(12, 70000, d, C, spread=spread, unit=unit)
+        assert _hip.knn_grid_plan(5000, 70000, d, 30, mode="pruned")["prunes"] == 1
+        assert _hip.knn_kernel_name(5000, 70000, d, 30, mode="pruned").endswith(", 2>")
+        if spread == 1.0 and not unit:      # separated clusters: most of the dense stream is skipped
+            _check(Q, R, 30, mode="pruned")
+            kept, dense = _hip.knn_prune_stats(5000, 70000, d, 30)
+            assert 0 < kept < 0.5 * dense
         R[100:140] = R[5]                   # duplicates
-        R[::997] *= 3.0                     # outliers far from every cluster
+        R[::997] *= 3.0                     # outliers far from every cluster (they inflate the cells' radii)
         Q[:7] = R[5]
-        tuning(ablate=64)
-        _check(Q, R, 30)
-        tuning(ablate=64, slots=8, tail_min_rows=1024)
-        _check(Q[:3300], R, 31)
-        tuning(ablate=64)
+        st = _check(Q, R, 30, mode="pruned")
+        kept, dense = _hip.knn_prune_stats(5000, 70000, d, 30)
+        assert 0 < kept <= dense
+        plain = _hip.knn_search(_dev(Q), _dev(R), 30, mode="dense")
+        assert torch.equal(plain.idx, st.idx) and torch.equal(plain.dist2, st.dist2)
+        tuning(slots=8, tail_min_rows=1024)  # several chunks per query block and a tail region
+        _check(Q[:3300], R, 31, mode="pruned")
+        tuning(cell_rows=128)                # 546 cells: cell numbers beyond one byte
+        assert _hip.knn_grid_plan(5000, 70000, d, 30, mode="pruned")["cells"] == 546
+        _check(Q, R, 30, mode="pruned")
+        tuning()
         idx_o, d2_o = oracle.knn_dist2(Q, R, 30)
         q, st = _dev(Q), None
         cuts = (0, 25000, 70000)
         for lo, hi in zip(cuts, cuts[1:]):
-            st = _hip.knn_search(q, _dev(R[lo:hi]), 30, col_offset=lo, state=st)
+            st = _hip.knn_search(q, _dev(R[lo:hi]), 30, col_offset=lo, state=st, mode="pruned")
         torch.cuda.synchronize()
         np.testing.assert_array_equal(st.idx.cpu().numpy(), idx_o)
         np.testing.assert_array_equal(st.dist2.cpu().numpy(), d2_o)
+
+
+def test_pruned_mode_on_structureless_data_and_where_it_does_not_apply():
+    """No clusters: every cell stays within reach, the table is still the oracle's.  Shapes the
+    pruned kernel does not serve (few rows, more than 64 features) run the dense search."""
+    rng = np.random.default_rng(17)
+    Q = rng.normal(size=(3000, 20)).astype(np.float32)
+    R = rng.normal(size=(20000, 20)).astype(np.float32)
+    _check(Q, R, 30, mode="pruned")
+    kept, dense = _hip.knn_prune_stats(3000, 20000, 20, 30)
+    assert kept > 0.9 * dense
+    assert _hip.knn_grid_plan(500, 3000, 20, 30, mode="pruned")["prunes"] == 0
+    _check(Q[:500], R[:3000], 30, mode="pruned")
+    assert _hip.knn_grid_plan(3000, 20000, 100, 30, mode="pruned")["prunes"] == 0
+    Qw, _ = _clustered(3, 3000, 100, 10)
+    Rw, _ = _clustered(4, 20000, 100, 10)
+    _check(Qw, Rw, 30, mode="pruned")
+    with pytest.raises(KeyError):
+        _hip.knn_search(_dev(Q), _dev(R), 30, mode="sparse")
+
+
+@pytest.mark.parametrize("d", [100, 128, 200, 256])
+def test_partition_serves_wide_rows(d, tuning):
+    """Beyond 64 features the partition kernels hold fewer rows per block and stream the pivots
+    through LDS in tiles; the table stays the oracle's and the plain caller-order stream's."""
+    Q, _ = _clustered(21, 2500, d, 9)
+    R, _ = _clustered(22, 18000, d, 9)
+    R[50:80] = R[3]
+    assert _hip.knn_grid_plan(2500, 18000, d, 30)["cells"] > 0
+    st = _check(Q, R, 30)
+    tuning(no_locality=True)
+    assert _hip.knn_grid_plan(2500, 18000, d, 30)["cells"] == 0
+    plain = _hip.knn_search(_dev(Q), _dev(R), 30)
+    assert torch.equal(plain.idx, st.idx) and torch.equal(plain.dist2, st.dist2)

@@ -33,15 +33,31 @@ def test_size_queries_and_argument_checks_without_gpu():
 
     lib = _hip.load_library()
     n = ctypes.c_size_t(0)
-    assert lib.scmiac_knn_workspace_size(1000, 2000, 50, 30, 0, ctypes.byref(n)) == 0
+    assert lib.scmiac_knn_workspace_size(1000, 2000, 50, 30, 0, 0, ctypes.byref(n)) == 0
     assert n.value > 1000 * 64 * 8
-    assert lib.scmiac_knn_workspace_size(10, 10, 500, 30, 0, ctypes.byref(n)) == 1
+    assert lib.scmiac_knn_workspace_size(10, 10, 500, 30, 0, 0, ctypes.byref(n)) == 1
     assert b"dimension" in lib.scmiac_last_error()
-    assert lib.scmiac_knn_workspace_size(10, 10, 50, 65, 0, ctypes.byref(n)) == 1
+    assert lib.scmiac_knn_workspace_size(10, 10, 50, 65, 0, 0, ctypes.byref(n)) == 1
+    # the search mode is an explicit argument: dense, pruned, nothing else
+    assert lib.scmiac_knn_workspace_size(1000, 2000, 50, 30, 0, 2, ctypes.byref(n)) == 1
+    assert b"SCMIAC_KNN_PRUNED" in lib.scmiac_last_error()
+    dense, pruned = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    assert lib.scmiac_knn_workspace_size(50000, 200000, 50, 30, 0, 0, ctypes.byref(dense)) == 0
+    assert lib.scmiac_knn_workspace_size(50000, 200000, 50, 30, 0, 1, ctypes.byref(pruned)) == 0
+    assert pruned.value > dense.value + 50000 * 195 * 4     # the query-to-pivot bounds of 195 cells
+    assert _hip.knn_grid_plan(50000, 200000, 50, 30, mode="pruned")["prunes"] == 1
+    assert _hip.knn_grid_plan(50000, 200000, 50, 30, mode="dense")["prunes"] == 0
+    assert _hip.knn_grid_plan(50000, 200000, 100, 30, mode="pruned")["prunes"] == 0   # beyond 64 features: dense
+    assert _hip.knn_grid_plan(50000, 200000, 100, 30)["cells"] == 195                # ... but partitioned
+    assert _hip.knn_kernel_name(50000, 200000, 50, 30, mode="pruned") == "fused_knn_kernel<25, 12, 320, 64, true, 2>"
+    assert _hip.knn_kernel_name(50000, 200000, 50, 30) == "fused_knn_kernel<25, 12, 320, 64, true, 0>"
+    off = ctypes.c_size_t(0)
+    assert lib.scmiac_knn_prune_stats_offset(50000, 200000, 50, 30, 0, ctypes.byref(off)) == 0 and 0 < off.value < pruned.value
+    assert lib.scmiac_knn_prune_stats_offset(500, 2000, 50, 30, 0, ctypes.byref(off)) == 1
     assert lib.scmiac_compact_workspace_size(12345, ctypes.byref(n)) == 0 and n.value >= 2 * 12345
     # the widened entry points: sizes and argument errors need no device either
-    assert lib.scmiac_knn_workspace_size(10, 10, 256, 30, 0, ctypes.byref(n)) == 0
-    assert lib.scmiac_knn_workspace_size(10, 10, 257, 30, 0, ctypes.byref(n)) == 1
+    assert lib.scmiac_knn_workspace_size(10, 10, 256, 30, 0, 0, ctypes.byref(n)) == 0
+    assert lib.scmiac_knn_workspace_size(10, 10, 257, 30, 0, 0, ctypes.byref(n)) == 1
     assert lib.scmiac_closer_count_workspace_size(5000, 7000, 30, ctypes.byref(n)) == 0 and n.value > 7000 * 30 * 4
     assert lib.scmiac_closer_count(None, 10, None, 11, 30, None, None, None, None, 0, None) == 1
     assert b"equal row counts" in lib.scmiac_last_error()

@@ -7,12 +7,11 @@ for wl, n, m in (("c2", None, None), ("c3", None, None), ("cca30", None, None), 
     U, V, _, _, d = bench.make_latents(wl, n, m)
     q, r = torch.from_numpy(U).cuda(), torch.from_numpy(V).cuda()
     res = {}
-    for name, ab in (("dense", 0), ("prune", 64)):
-        _hip.set_tuning(ablate=ab)
-        st = _hip.knn_search(q, r, 30); torch.cuda.synchronize()
+    for name, mode in (("dense", "dense"), ("prune", "pruned")):
+        st = _hip.knn_search(q, r, 30, mode=mode); torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(3):
-            st = _hip.knn_search(q, r, 30)
+            st = _hip.knn_search(q, r, 30, mode=mode)
         torch.cuda.synchronize()
         res[name] = ((time.perf_counter() - t0) / 3 * 1e3, st.idx.clone(), st.dist2.clone(), int(st.n_uncertified.item()))
     _hip.set_tuning()
