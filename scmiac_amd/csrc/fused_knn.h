@@ -584,8 +584,8 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
             order = my_order;
             T_loop = oN + n_own;
             pruning = true;
-            if (n_own == 0) plan_rest();        // nothing of its own left in this chunk: decide at once
-            else replan_at = T_loop - 1;        // ... else while the last own stage is being fetched
+            if (T_loop == 0) plan_rest();       // nothing of its own in this chunk: decide at once
+            else replan_at = T_loop - 1;        // ... else while the last home / own stage is being fetched
         }
     }
 

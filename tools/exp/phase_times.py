@@ -3,7 +3,7 @@
 stream, closing merges -- from the diagnostic instantiation's per-wave timestamps, for the main
 region and the tail region of the grid apart.
 
-    python tools/exp/phase_times.py [workload[:n] ...]      (default: c2 c4 c3:125000)
+    python tools/exp/phase_times.py [workload[:n[:pruned]] ...]      (default: c2 c4 c3:125000)
 """
 import sys
 from pathlib import Path
@@ -17,7 +17,7 @@ from scmiac_amd import _hip  # noqa: E402
 import bench  # noqa: E402
 
 
-def report(name, n_override, tuning=None):
+def report(name, n_override, tuning=None, mode="dense"):
     U, V, _, _, d = bench.make_latents(name, n_override, None)
     q, r = torch.from_numpy(U).cuda(), torch.from_numpy(V).cuda()
     n, m, k = q.shape[0], r.shape[0], 30
@@ -25,22 +25,24 @@ def report(name, n_override, tuning=None):
     _hip.set_tuning(**tuning)
     for _ in range(2):
         _hip.set_timing(True)
-        _hip.knn_search(q, r, k)
+        _hip.knn_search(q, r, k, mode=mode)
         ms_prod, _ = _hip.fused_ms()
         _hip.set_timing(False)
     _hip.set_tuning(diag=True, **tuning)
     _hip.set_timing(True)
-    _hip.knn_search(q, r, k)
+    _hip.knn_search(q, r, k, mode=mode)
     ms_diag, _ = _hip.fused_ms()
     _hip.set_timing(False)
-    plan = _hip.knn_grid_plan(n, m, d, k)
-    dg = _hip.knn_diag(n, m, d, k).astype(np.float64)
+    plan = _hip.knn_grid_plan(n, m, d, k, mode=mode)
+    dg = _hip.knn_diag(n, m, d, k, mode=mode).astype(np.float64)
+    if plan["prunes"]:
+        print("   pruned search: stages streamed / dense", _hip.knn_prune_stats(n, m, d, k))
     _hip.set_tuning()
     nw = plan["queries_per_block"] // 32
     blocks = dg.reshape(-1, nw, 16)
     block0 = plan["main_query_blocks"] * plan["S"]
     flops = 2.0 * n * m * d
-    print(f"== {name} n={n} m={m} d={d} {tuning or ''}: product kernel {ms_prod:.3f} ms = {flops / ms_prod / 1e9 / 157.3 * 100:.1f} % of peak, "
+    print(f"== {name} n={n} m={m} d={d} {mode} {tuning or ''}: product kernel {ms_prod:.3f} ms = {flops / ms_prod / 1e9 / 157.3 * 100:.1f} % of peak, "
           f"diagnostic kernel {ms_diag:.3f} ms; plan {plan}")
     for label, b in (("main", blocks[:block0]), ("tail", blocks[block0:])):
         if len(b) == 0:
@@ -63,5 +65,5 @@ def report(name, n_override, tuning=None):
 
 if __name__ == "__main__":
     for spec in (sys.argv[1:] or ["c2", "c4", "c3:125000"]):
-        name, _, n = spec.partition(":")
-        report(name, int(n) if n else None)
+        name, n, mode = (spec.split(":") + ["", ""])[:3]
+        report(name, int(n) if n else None, mode=mode or "dense")
