@@ -299,9 +299,12 @@ SCMIAC_API int scmiac_closer_count(const float *q, int64_t n, const float *r, in
  * TruncatedSVD, which scmiac/preprocessing/anchors.py:196-198 calls.  pivots [m] int32 are
  * LAPACK's 1-based row interchanges (torch.linalg.lu_factor's second result), n the number
  * of rows; perm [n] int64 receives the identity with the interchanges applied in order
- * (perm[i] <-> perm[pivots[i]-1], i = 0..m-1), so that (P L)[perm] = L.
+ * (perm[i] <-> perm[pivots[i]-1], i = 0..m-1), so that (P L)[perm] = L.  An entry of pivots
+ * outside 1..n is no LAPACK pivot (a factorisation of non-finite input leaves such entries): it
+ * is skipped and *status (int32, device, may be NULL; never cleared here) becomes 1.
  */
-SCMIAC_API int scmiac_lu_row_perm(const int32_t *pivots, int m, int64_t n, int64_t *perm, void *stream);
+SCMIAC_API int scmiac_lu_row_perm(const int32_t *pivots, int m, int64_t n, int64_t *perm, int32_t *status,
+                                  void *stream);
 
 /*
  * Symmetric NT-Xent loss between the two embeddings of a batch of anchor cells:

@@ -44,7 +44,7 @@ _SIGNATURES = {
     "scmiac_knn_prune_stats_offset": ([_i64, _i64, _i32, _i32, _i32, _c.POINTER(_sz)], _c.c_int),
     "scmiac_knn_grid_plan": ([_i64, _i64, _i32, _i32, _i32, _i32, _c.POINTER(_i64)], _c.c_int),
     "scmiac_knn_kernel_name": ([_i64, _i64, _i32, _i32, _i32, _i32, _c.c_char_p, _sz], _c.c_int),
-    "scmiac_lu_row_perm": ([_vp, _i32, _i64, _vp, _vp], _c.c_int),
+    "scmiac_lu_row_perm": ([_vp, _i32, _i64, _vp, _vp, _vp], _c.c_int),
     "scmiac_knn_set_timing": ([_i32], _c.c_int),
     "scmiac_knn_set_tuning": ([_i32] * 13, _c.c_int),
     "scmiac_knn_fused_ms": ([_c.POINTER(_c.c_float), _c.POINTER(_c.c_int)], _c.c_int),
@@ -417,15 +417,18 @@ def ntxent2_backward(zi, zj, temperature, lse_row, lse_col, grad_out):
     return dzi, dzj
 
 
-def lu_row_perm(pivots, n):
+def lu_row_perm(pivots, n, status=None):
     """Row permutation of a pivoted LU (``torch.linalg.lu_factor``'s 1-based int32 pivots of an
-    ``n``-row block) as an int64 device tensor, without a trip to the host."""
+    ``n``-row block) as an int64 device tensor, without a trip to the host.  ``status`` (one int32
+    on the device, zeroed by the caller) becomes 1 when an entry is no pivot of an ``n``-row block."""
     lib = require_gpu()
     device = _cuda_device(pivots, "pivots")
     pivots = _dev_i32(pivots, device)
+    if status is not None:
+        _cuda_device(status, "status")
     perm = torch.empty((n,), dtype=torch.int64, device=device)
     with _on_device(device):
-        _check(lib.scmiac_lu_row_perm(_ptr(pivots), pivots.shape[0], n, _ptr(perm), _stream()))
+        _check(lib.scmiac_lu_row_perm(_ptr(pivots), pivots.shape[0], n, _ptr(perm), _ptr(status), _stream()))
     return perm
 
 

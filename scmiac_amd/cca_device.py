@@ -66,15 +66,15 @@ class DeviceScaler:
         return (x - self.mean_) / self.scale_
 
 
-def _lu_rows(y):
+def _lu_rows(y, status=None):
     """``P @ L`` of the partially pivoted LU factorisation of a tall block
-    (what ``scipy.linalg.lu(y, permute_l=True)[0]`` returns)."""
+    (what ``scipy.linalg.lu(y, permute_l=True)[0]`` returns).  ``status``: see ``_hip.lu_row_perm``."""
     n, r = y.shape
     m = min(n, r)
     lu, piv = torch.linalg.lu_factor(y)
     low = torch.tril(lu[:, :m], diagonal=-1)
     low[:m].diagonal().fill_(1.0)
-    perm = _hip.lu_row_perm(piv[:m], n)  # row swaps in the order LAPACK applied them, applied on the device
+    perm = _hip.lu_row_perm(piv[:m], n, status)  # row swaps in the order LAPACK applied them, applied on the device
     out = torch.empty_like(low)
     out[perm] = low
     return out
@@ -103,15 +103,20 @@ def randomized_svd_of_product(t1, t2, n_components, random_state=0, n_iter=N_ITE
     def mt_dot(y):     # M.T @ y
         return b @ (a.T @ y)
 
+    bad_pivot = torch.zeros((1,), dtype=torch.int32, device=t1.device)
     for _ in range(n_iter):
-        q = _lu_rows(m_dot(q))
-        q = _lu_rows(mt_dot(q))
+        q = _lu_rows(m_dot(q), bad_pivot)
+        q = _lu_rows(mt_dot(q), bad_pivot)
     q, _ = torch.linalg.qr(m_dot(q), mode="reduced")
 
     # B = Q.T @ M is r x cols(M); its SVD through a QR of B.T keeps the long side on the device
     bt = mt_dot(q)                                   # cols(M) x r
     q2, r2 = torch.linalg.qr(bt, mode="reduced")     # B = r2.T @ q2.T
-    uh, s, wt = np.linalg.svd(r2.T.cpu().numpy(), full_matrices=False)
+    r2_host = r2.T.cpu().numpy()                     # (the one visit to the host: everything above has run)
+    if int(bad_pivot.item()):
+        raise ValueError("the LU factorisations of the range finder returned pivots outside their blocks "
+                         "(non-finite values in the input matrices?)")
+    uh, s, wt = np.linalg.svd(r2_host, full_matrices=False)
     uh = torch.from_numpy(np.ascontiguousarray(uh)).to(t1.device)
     wt = torch.from_numpy(np.ascontiguousarray(wt)).to(t1.device)
     u_m = (q @ uh)[:, :n_components]                 # left vectors of M

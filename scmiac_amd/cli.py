@@ -62,14 +62,18 @@ def _join_ranks():
     return dist.get_rank(), world
 
 
-def _leave_ranks():
+def _leave_ranks(failed=False):
+    """Back to a plain process.  After an error on this rank there is no barrier: the other ranks
+    may be waiting in a collective this rank will never join, and the launcher ends them when this
+    process exits with its error."""
     import torch.distributed as dist
 
     from . import sharded
 
     sharded.use_process_group(enable=False)
-    dist.barrier()
-    dist.destroy_process_group()
+    if not failed:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def write_anchors(anchor_df, output_dir) -> Path:
@@ -88,17 +92,28 @@ def run_train(args: argparse.Namespace) -> int:
 
     adata_rna = _read_h5ad(args.rna_h5ad)
     adata_atac = _read_h5ad(args.atac_h5ad)
+    if args.search_mode != "dense":
+        from . import _hip
+        _hip.set_default_mode(args.search_mode)
 
-    rank, world = _join_ranks()  # under torchrun: one rank per GPU, the searches shared out over them
+    # Under torchrun: one rank per GPU.  Every rank reads both files and runs the whole stage (gene
+    # selection, CCA, scoring and filter replicated); only the k-NN tables' query rows are shared
+    # out over the ranks.
+    rank, world = _join_ranks()
     print("Generating MNN anchors...")
-    anchor_df = find_anchors(
-        adata_rna, adata_atac,
-        all_nfeatures=args.all_nfeatures, single_nfeatures=args.single_nfeatures,
-        k_anchor=args.k_anchor, n_components=args.n_components,
-        ct_filter=True,  # the command always filters by cell type, like the reference's
-        mode=args.mode,
-        rna_celltype_key=args.rna_celltype_key, atac_celltype_key=args.atac_celltype_key,
-    )
+    try:
+        anchor_df = find_anchors(
+            adata_rna, adata_atac,
+            all_nfeatures=args.all_nfeatures, single_nfeatures=args.single_nfeatures,
+            k_anchor=args.k_anchor, n_components=args.n_components,
+            ct_filter=True,  # the command always filters by cell type, like the reference's
+            mode=args.mode,
+            rna_celltype_key=args.rna_celltype_key, atac_celltype_key=args.atac_celltype_key,
+        )
+    except BaseException:
+        if world > 1:
+            _leave_ranks(failed=True)
+        raise
     if world > 1:
         _leave_ranks()
         if rank != 0:  # every rank holds the same table: one of them writes it and goes on
@@ -125,6 +140,20 @@ def _continue_with_reference(reference, args, adata_rna, adata_atac, anchor_df) 
         rna_latent_key=args.rna_latent_key, atac_latent_key=args.atac_latent_key,
         batch_size=args.batch_size, hidden_dims=args.hidden_dims, latent_dim=args.latent_dim,
         balanced_sampler=args.balanced_sampler, device=args.device)
+    if args.device_consumer:
+        # the reference's training loop, fed by this package's device-resident loaders and fused
+        # anchor loss: train_model iterates whatever loaders it is handed (scmiac.py:239) and looks
+        # its loss class up in its own module (scmiac.py:219), so neither needs an edit of scMIAC
+        import importlib
+
+        from .modeling import dataset as device_dataset
+        from .modeling.loss import NTXentLoss2
+
+        all_cells_loader, anchor_cells_loader = device_dataset.make_loaders(
+            adata_rna, adata_atac, anchor_df, rna_latent_key=args.rna_latent_key,
+            atac_latent_key=args.atac_latent_key, batch_size=args.batch_size,
+            balanced_sampler=args.balanced_sampler, device=args.device)
+        importlib.import_module(reference.train_model.__module__).NTXentLoss2 = NTXentLoss2
     rna_vae, atac_vae = reference.train_model(
         rna_vae, atac_vae, all_cells_loader, anchor_cells_loader, device=args.device,
         num_epoches=args.num_epochs, lambda_rna_kl=args.lambda_rna_kl, lambda_atac_kl=args.lambda_atac_kl,
@@ -182,6 +211,13 @@ def build_parser() -> argparse.ArgumentParser:
                        help="v: the two files hold the same cells in the same order; pair them by position, no search")
     train.add_argument("--no-balanced-sampler", dest="balanced_sampler", action="store_false", default=True,
                        help="draw anchor batches uniformly instead of weighting by 1 / cell-type frequency")
+    # two options the reference does not have (its scripts never pass them; the defaults keep its behaviour)
+    train.add_argument("--search-mode", choices=["dense", "pruned"], default="dense",
+                       help="how the exact k-NN search goes through the cells: every query against every cell, or "
+                            "only the pivot cells that can hold a neighbour (same tables, much faster on clustered data)")
+    train.add_argument("--device-consumer", action="store_true", default=False,
+                       help="with scMIAC installed: feed its training loop from device-resident loaders and the fused "
+                            "anchor loss of this package instead of its DataLoaders and eager loss")
     train.set_defaults(func=run_train)
     return top
 

@@ -399,11 +399,11 @@ int scmiac_anchor_filter(const int64_t* pairs, const int64_t* n_pairs, int64_t n
     return SCMIAC_OK;
 }
 
-int scmiac_lu_row_perm(const int32_t* pivots, int m, int64_t n, int64_t* perm, void* stream_) {
+int scmiac_lu_row_perm(const int32_t* pivots, int m, int64_t n, int64_t* perm, int32_t* status, void* stream_) {
     if (m < 0 || n < 0 || m > n) return fail(SCMIAC_ERR_ARG, "need 0 <= m <= n (m=%d, n=%lld)", m, (long long)n);
     if (n == 0) return SCMIAC_OK;
     if (!perm || (m > 0 && !pivots)) return fail(SCMIAC_ERR_ARG, "NULL device pointer");
-    HIP_TRY(launch_lu_row_perm(pivots, m, n, reinterpret_cast<long long*>(perm), static_cast<hipStream_t>(stream_)),
+    HIP_TRY(launch_lu_row_perm(pivots, m, n, reinterpret_cast<long long*>(perm), status, static_cast<hipStream_t>(stream_)),
             "lu_row_perm");
     return SCMIAC_OK;
 }

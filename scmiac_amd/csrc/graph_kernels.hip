@@ -369,26 +369,34 @@ hipError_t launch_anchor_filter(const long long* pairs, const long long* n_pairs
 }
 
 // ------------------------------------------------------------------ LU row permutation
-// perm[0..n) <- identity, then LAPACK's row interchanges in order: swap(perm[i], perm[piv[i]-1])
-// for i = 0..m-1 (m is the number of columns of a tall block: a few dozen).  The swaps depend on
-// each other, so one thread applies them; the identity fill uses the whole block.
-__global__ __launch_bounds__(256) void lu_row_perm_kernel(const int* __restrict__ piv, int m, long long n,
-                                                          long long* __restrict__ perm) {
-    for (long long i = threadIdx.x; i < n; i += blockDim.x) perm[i] = i;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int i = 0; i < m; ++i) {
-            long long p = (long long)piv[i] - 1;
-            if (p < 0 || p >= n) continue;  // not a LAPACK pivot: leave the row where it is
-            const long long a = perm[i], b = perm[p];
-            perm[i] = b;
-            perm[p] = a;
-        }
+// perm[0..n) <- identity (all blocks), then LAPACK's row interchanges in order:
+// swap(perm[i], perm[piv[i]-1]) for i = 0..m-1 (m is the number of columns of a tall block: a few
+// dozen).  The swaps depend on each other, so one thread of a second, one-block launch applies
+// them.  A pivot outside 1..n is no LAPACK pivot (a factorisation of NaNs leaves such entries):
+// it is skipped and *status becomes 1, so that the caller can refuse the result.
+__global__ __launch_bounds__(256) void identity_perm_kernel(long long n, long long* __restrict__ perm) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        perm[i] = i;
+}
+__global__ void lu_row_swaps_kernel(const int* __restrict__ piv, int m, long long n, long long* __restrict__ perm,
+                                    int* __restrict__ status) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    bool bad = false;
+    for (int i = 0; i < m; ++i) {
+        const long long p = (long long)piv[i] - 1;
+        if (p < 0 || p >= n) { bad = true; continue; }
+        const long long a = perm[i], b = perm[p];
+        perm[i] = b;
+        perm[p] = a;
     }
+    if (bad && status != nullptr) *status = 1;
 }
 
-hipError_t launch_lu_row_perm(const int* piv, int m, long long n, long long* perm, hipStream_t stream) {
-    hipLaunchKernelGGL(lu_row_perm_kernel, dim3(1), dim3(256), 0, stream, piv, m, n, perm);
+hipError_t launch_lu_row_perm(const int* piv, int m, long long n, long long* perm, int* status, hipStream_t stream) {
+    long long blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(identity_perm_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, n, perm);
+    hipLaunchKernelGGL(lu_row_swaps_kernel, dim3(1), dim3(64), 0, stream, piv, m, n, perm, status);
     return hipGetLastError();
 }
 

@@ -198,7 +198,7 @@ hipError_t launch_anchor_filter(const long long* pairs, const long long* n_pairs
                                 long long* out_index, long long* counts, double* all_score, void* ws,
                                 hipStream_t stream);
 
-hipError_t launch_lu_row_perm(const int* piv, int m, long long n, long long* perm, hipStream_t stream);
+hipError_t launch_lu_row_perm(const int* piv, int m, long long n, long long* perm, int* status, hipStream_t stream);
 
 // count_kernels.hip: references closer than the true match, per query row
 size_t closer_count_pend_bytes(const KnnGeometry& g);

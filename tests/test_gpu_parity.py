@@ -492,9 +492,18 @@ def test_lu_row_permutation_on_the_device():
         got = _lu_rows(torch.from_numpy(y).cuda()).cpu().numpy()
         want = scipy.linalg.lu(y, permute_l=True)[0]
         np.testing.assert_allclose(got, want, rtol=0, atol=1e-12)
-    # pivots outside the block are refused before the launch, entries outside 1..n are left alone
+    # more pivots than rows are refused before the launch; an entry outside 1..n is skipped and reported
     piv = torch.tensor([3, 99, 2], dtype=torch.int32, device="cuda")
-    perm = _hip.lu_row_perm(piv, 4).cpu().numpy()
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    perm = _hip.lu_row_perm(piv, 4, status).cpu().numpy()
     np.testing.assert_array_equal(perm, [2, 0, 1, 3])
+    assert int(status.item()) == 1
+    status.zero_()
+    _hip.lu_row_perm(torch.tensor([3, 2, 3], dtype=torch.int32, device="cuda"), 300000, status)
+    assert int(status.item()) == 0
+    from scmiac_amd.cca_device import randomized_svd_of_product
+    bad = torch.full((500, 40), float("nan"), dtype=torch.float64, device="cuda")
+    with pytest.raises(ValueError):  # refused pivots, or LAPACK's own complaint about the NaNs (a ValueError too)
+        randomized_svd_of_product(bad, bad.clone(), 5)
     with pytest.raises(ValueError):
         _hip.lu_row_perm(torch.ones(5, dtype=torch.int32, device="cuda"), 3)
