@@ -85,7 +85,8 @@ static KnnWs knn_carve(void* ws, long long n, long long m, int d, const KnnGeome
         w.loc.cstart_r = reinterpret_cast<int*>(take(sizeof(int) * 2 * (size_t)(g.cells + 1)));
         w.loc.perm_q = reinterpret_cast<int*>(take(sizeof(int) * (size_t)n));
         w.loc.perm_r = reinterpret_cast<int*>(take(sizeof(int) * (size_t)m));
-        w.loc.home = reinterpret_cast<int*>(take(sizeof(int) * 2 * (size_t)g.nqb));
+        w.loc.home = reinterpret_cast<int*>(take(sizeof(int) * 4 * (size_t)g.nqb));
+        w.loc.piv_rows = reinterpret_cast<int*>(take(sizeof(int) * 2 * (size_t)g.cells_pad));
         if (g.prune) {  // pruned search: distances to the pivots, cell radii, per-block stage lists, counters
             w.loc.qpd = reinterpret_cast<float*>(take(sizeof(float) * (size_t)g.cells_pad * (size_t)n));
             w.loc.crad = reinterpret_cast<unsigned*>(take(sizeof(unsigned) * (size_t)g.cells_pad));
@@ -93,8 +94,7 @@ static KnnWs knn_carve(void* ws, long long n, long long m, int d, const KnnGeome
             const long long longest = g.chunk_rows > g.tail.chunk_rows ? g.chunk_rows : g.tail.chunk_rows;
             w.loc.order_stride = (int)(longest / g.RT + 1);
             size_t order_bytes = sizeof(unsigned short) * (size_t)g.blocks * (size_t)w.loc.order_stride;
-            if (order_bytes < sizeof(int) * (size_t)g.cells_pad) order_bytes = sizeof(int) * (size_t)g.cells_pad;
-            w.loc.order = reinterpret_cast<unsigned short*>(take(order_bytes));  // (its head first holds the pivots' rows)
+            w.loc.order = reinterpret_cast<unsigned short*>(take(order_bytes));
             w.stats_offset = off;
             w.loc.stats = reinterpret_cast<unsigned long long*>(take(2 * sizeof(unsigned long long)));
         }

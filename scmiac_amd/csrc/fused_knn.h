@@ -113,7 +113,7 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
     u64* __restrict__ lists,          // [S][n_pad][64], then the tail region's extra lists
     uint2* __restrict__ pend_g,       // [shortlists][PCAP] pending candidates (GP_ only)
     long long n, long long n_pad, int nqb, long long chunk_rows, FusedTail tail, int kt, int ablate_in,
-    const int* __restrict__ home,     // [nqb][2] home stages of every query block, or NULL
+    const int* __restrict__ home,     // [nqb][4] home window and own cells of every query block (stages), or NULL
     int seed_stages,                  // most home stages the seed pass looks at
     const float* __restrict__ tau0,   // [n_pad] threshold to start from, or NULL
     float* __restrict__ tau_out,      // [shortlists] threshold each shortlist ended with
@@ -179,8 +179,8 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
     // inside the chunk first -- their near neighbours, which bring the thresholds down to where
     // they will stay -- then the rest.
     const int G0 = (int)(r_begin / RT);
-    int H0 = 0, HN = 0;
-    if (home != nullptr && T > 0) { H0 = home[2 * qb]; HN = home[2 * qb + 1]; }
+    int H0 = 0, HN = 0, OW0 = 0, OWN = 0;  // home window; the queries' own cells inside it
+    if (home != nullptr && T > 0) { H0 = home[4 * qb]; HN = home[4 * qb + 1]; OW0 = home[4 * qb + 2]; OWN = home[4 * qb + 3]; }
     int O0 = H0 > G0 ? H0 : G0;                                  // home stages inside the chunk: [O0, O0 + oN)
     const int O1 = (H0 + HN < G0 + T) ? H0 + HN : G0 + T;
     const int oN = O1 > O0 ? O1 - O0 : 0;
@@ -189,11 +189,11 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
     // (each stage then comes out of the L2 for all but the first of them), although their seed
     // passes and home stages differ in length: a block that has spent `shift` stage times on
     // those enters the rest of its chunk `shift` stages in and wraps round at the end.
-    int SN = (home != nullptr && T > 0) ? (HN < seed_stages ? HN : seed_stages) : 0;  // seed pass stages
+    int SN = (home != nullptr && T > 0) ? (OWN < seed_stages ? OWN : seed_stages) : 0;  // seed pass stages (own cells' head)
     // (pruned search: the reach test needs a threshold that every query has earned among its own
     // cell's rows.  A chunk that holds those rows streams them before the test; a block whose chunk
     // does not -- one of several chunks of a query block -- looks at all of them in its seed pass.)
-    if (PRUNE_ && prune.qpd != nullptr && SN > 0 && !(H0 >= G0 && H0 + HN <= G0 + T)) SN = HN;
+    if (PRUNE_ && prune.qpd != nullptr && SN > 0 && !(OW0 >= G0 && OW0 + OWN <= G0 + T)) SN = OWN;
     const int rest = T - oN;
     const int shift = rest > 0 ? (SN + oN) % rest : 0;
     // (pruned search: after its seed pass a block may decide to stream only part of the rest
@@ -407,14 +407,14 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
         float gmin[2][16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) { gmin[0][r] = tau_max; gmin[1][r] = tau_max; }
-        SCMIAC_STAGE((long long)H0 * RT, 0);
+        SCMIAC_STAGE((long long)OW0 * RT, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         for (int t = 0; t < SN; ++t) {
-            if (t + 1 < SN) SCMIAC_STAGE((long long)(H0 + t + 1) * RT, (t + 1) & 1);
+            if (t + 1 < SN) SCMIAC_STAGE((long long)(OW0 + t + 1) * RT, (t + 1) & 1);
             const float* tb = tile + (t & 1) * RT * LS;
             const float* nb = tnorm + (t & 1) * RT;
-            const long long cur_row0 = (long long)(H0 + t) * RT;
+            const long long cur_row0 = (long long)(OW0 + t) * RT;
             SCMIAC_LOAD_NORMS(0, 0);
             SCMIAC_LOAD_GROUP(0, 0, 0);
             SCMIAC_LOAD_GROUP(0, 1, 1);

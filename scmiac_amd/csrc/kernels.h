@@ -64,7 +64,8 @@ struct LocalityWs {
     int* cstart_r;          // [2 (cells + 1)]
     int* perm_q;            // [n]: packed query position -> caller's row
     int* perm_r;            // [m]: packed reference row -> caller's row
-    int* home;              // [nqb][2]
+    int* home;              // [nqb][4]: home window (first stage, stages), own cells inside it (first stage, stages)
+    int* piv_rows;          // [2 cells_pad]: rows of the pivots as chosen, then in chain order
     // pruned search only (NULL otherwise)
     float* qpd;             // [cells_pad][n]: lower bound of dist(query row, pivot)
     unsigned* crad;         // [cells_pad]: float bits, upper bound of max dist(reference row, its pivot)

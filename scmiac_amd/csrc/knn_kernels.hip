@@ -164,6 +164,72 @@ __global__ __launch_bounds__(FPS_NT) void fps_pivots_kernel(const float* __restr
     }
 }
 
+// Order of the cells in the packed images: a greedy nearest-neighbour chain over the pivots (start
+// at pivot 0, go on to the nearest pivot not yet visited), so that the cells of one cluster of the
+// data -- whose pivots are closer to each other than to any other cluster's -- follow each other.
+// A query block's home window, a run of consecutive packed rows round its own cells, then holds its
+// cluster-mates in the neighbouring cells too.  rows_in: the pivots' rows (NULL: row c * m / C);
+// rows_out[pos] = row of the pos-th pivot of the chain.  One block; C steps of C distances each.
+static constexpr int CHAIN_NT = 1024;
+__global__ __launch_bounds__(CHAIN_NT) void chain_order_kernel(const float* __restrict__ R, long long m, int d, int C,
+                                                               const int* __restrict__ rows_in, int* __restrict__ rows_out,
+                                                               int lds_cells /* pivots cached in LDS: C or 0 */) {
+    extern __shared__ __attribute__((aligned(16))) float chs[];
+    float* pT = chs;                                   // [d][C] when lds_cells == C
+    __shared__ float cur_f[SCMIAC_KNN_MAX_D_INTERNAL];
+    __shared__ float red_v[CHAIN_NT / 64];
+    __shared__ int red_i[CHAIN_NT / 64];
+    __shared__ int cur;
+    __shared__ unsigned char visited[KNN_MAX_CELLS];
+    const int tid = threadIdx.x;
+    auto row_of = [&](int c) { return rows_in != nullptr ? (long long)rows_in[c] : (long long)c * m / C; };
+    for (int c = tid; c < C; c += CHAIN_NT) visited[c] = 0;
+    if (lds_cells == C)
+        for (int e = tid; e < C * d; e += CHAIN_NT) {
+            const int c = e / d, i = e - c * d;
+            pT[i * C + c] = R[row_of(c) * d + i];
+        }
+    if (tid == 0) { cur = 0; visited[0] = 1; rows_out[0] = (int)row_of(0); }
+    __syncthreads();
+    for (int step = 1; step < C; ++step) {
+        const long long crow = row_of(cur);
+        for (int i = tid; i < d; i += CHAIN_NT) cur_f[i] = R[crow * d + i];
+        __syncthreads();
+        float best = __builtin_inff();
+        int besti = -1;
+        for (int c = tid; c < C; c += CHAIN_NT) {
+            if (visited[c]) continue;
+            float acc = 0.0f;
+            if (lds_cells == C) {
+                for (int i = 0; i < d; ++i) { const float t = pT[i * C + c] - cur_f[i]; acc = __fmaf_rn(t, t, acc); }
+            } else {
+                const float* row = R + row_of(c) * d;
+                for (int i = 0; i < d; ++i) { const float t = row[i] - cur_f[i]; acc = __fmaf_rn(t, t, acc); }
+            }
+            if (!(acc == acc)) acc = 3.0e38f;  // (a pivot with NaNs is visited last)
+            if (acc < best) { best = acc; besti = c; }
+        }
+        for (int off = 32; off; off >>= 1) {
+            const float ov = __shfl_xor(best, off);
+            const int oi = __shfl_xor(besti, off);
+            if (oi >= 0 && (besti < 0 || ov < best || (ov == best && oi < besti))) { best = ov; besti = oi; }
+        }
+        if ((tid & 63) == 0) { red_v[tid >> 6] = best; red_i[tid >> 6] = besti; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < CHAIN_NT / 64; ++w) {
+                const float ov = red_v[w];
+                const int oi = red_i[w];
+                if (oi >= 0 && (besti < 0 || ov < best || (ov == best && oi < besti))) { best = ov; besti = oi; }
+            }
+            cur = besti;             // (step < C: at least one pivot is unvisited)
+            visited[besti] = 1;
+            rows_out[step] = (int)row_of(besti);
+        }
+        __syncthreads();
+    }
+}
+
 // pivT[i][c] = feature i of pivot c (= row (c * m) / C of R, or row piv_rows[c]), pnorm[c] = |pivot c|^2
 __global__ void pivots_kernel(const float* __restrict__ R, long long m, int d, int C, int Cpad,
                               float* __restrict__ pivT, float* __restrict__ pnorm, const int* __restrict__ piv_rows) {
@@ -340,8 +406,11 @@ __global__ __launch_bounds__(256) void cell_scatter_kernel(const cell_t* __restr
     perm[cell_start[mine] + blockoff[(long long)blockIdx.x * C + mine] + before] = (int)row;
 }
 
-// home[b] = {first stage, number of stages} of the reference rows that share a cell with
-// query block b's queries (at most max_stages of them)
+// home[b] = {first stage, stages} of query block b's home window and {first stage, stages} of its
+// own cells inside it.  The own cells are the reference rows that share a cell with the block's
+// queries; the window is that range widened, evenly to both sides, to max_stages stages of
+// consecutive packed rows -- the neighbouring cells of the chain order, i.e. the rest of the
+// queries' cluster.  (Own cells longer than the window: the window is their head.)
 __global__ void home_stages_kernel(const cell_t* __restrict__ qcell, const int* __restrict__ perm_q,
                                    long long n, int qpb, int nqb, const int* __restrict__ rcell_start, int RT,
                                    long long m_pad, int max_stages, int* __restrict__ home) {
@@ -350,18 +419,25 @@ __global__ void home_stages_kernel(const cell_t* __restrict__ qcell, const int* 
     const long long first = (long long)b * qpb;
     long long last = first + qpb - 1;
     if (last > n - 1) last = n - 1;
-    int s0 = 0, sn = 0;
+    int w0 = 0, wn = 0, o0 = 0, on = 0;
     if (first < n) {
         const int c_lo = qcell[perm_q[first]], c_hi = qcell[perm_q[last]];
         const long long r0 = rcell_start[c_lo], r1 = rcell_start[c_hi + 1];
-        s0 = (int)(r0 / RT);
-        long long s1 = (r1 + RT - 1) / RT;
+        const long long total = m_pad / RT;
+        long long s0 = r0 / RT, s1 = (r1 + RT - 1) / RT;
+        if (s1 > total) s1 = total;
         if (s1 > s0 + max_stages) s1 = s0 + max_stages;
-        if (s1 > m_pad / RT) s1 = m_pad / RT;
-        sn = s1 > s0 ? (int)(s1 - s0) : 0;
+        if (s1 > s0) {
+            o0 = (int)s0; on = (int)(s1 - s0);
+            long long spare = max_stages - (s1 - s0);   // stages the window may add round the own cells
+            long long a = s0 - spare / 2, z = s1 + (spare - spare / 2);
+            if (a < 0) { z -= a; a = 0; }
+            if (z > total) { a -= z - total; z = total; }
+            if (a < 0) a = 0;
+            w0 = (int)a; wn = (int)(z - a);
+        }
     }
-    home[2 * b] = s0;
-    home[2 * b + 1] = sn;
+    home[4 * b] = w0; home[4 * b + 1] = wn; home[4 * b + 2] = o0; home[4 * b + 3] = on;
 }
 
 // Merge mode: a threshold to start from.  The running result's k-th distance D_k bounds what
@@ -886,10 +962,19 @@ int knn_cell_block_rows(int d) { return cell_rows_per_block(d); }
 hipError_t launch_locality(const float* Q, long long n, const float* R, long long m, int d, const KnnGeometry& g,
                            const LocalityWs& w, hipStream_t stream) {
     const int* piv_rows = nullptr;
-    if (g.prune && w.crad != nullptr) {  // (the row numbers pass through the head of the stage-list region)
-        int* rows = reinterpret_cast<int*>(w.order);
-        hipLaunchKernelGGL(fps_pivots_kernel, dim3(1), dim3(FPS_NT), 0, stream, R, m, d, g.cells, rows);
-        piv_rows = rows;
+    if (g.prune && w.crad != nullptr) {
+        hipLaunchKernelGGL(fps_pivots_kernel, dim3(1), dim3(FPS_NT), 0, stream, R, m, d, g.cells, w.piv_rows);
+        piv_rows = w.piv_rows;
+    }
+    {   // the cells in chain order (the pivots cached in LDS when they fit)
+        const size_t lds = sizeof(float) * (size_t)g.cells * d;
+        const bool fits = lds <= 96 * 1024;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_order_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(fits ? lds : 0));
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(chain_order_kernel, dim3(1), dim3(CHAIN_NT), fits ? lds : 0, stream, R, m, d, g.cells, piv_rows,
+                           w.piv_rows + g.cells_pad, fits ? g.cells : 0);
+        piv_rows = w.piv_rows + g.cells_pad;
     }
     hipLaunchKernelGGL(pivots_kernel, dim3((unsigned)((g.cells_pad + 63) / 64)), dim3(64), 0, stream, R, m, d, g.cells,
                        g.cells_pad, w.pivT, w.pnorm, piv_rows);

@@ -503,7 +503,7 @@ def test_lu_row_permutation_on_the_device():
     assert int(status.item()) == 0
     from scmiac_amd.cca_device import randomized_svd_of_product
     bad = torch.full((500, 40), float("nan"), dtype=torch.float64, device="cuda")
-    with pytest.raises(ValueError):  # refused pivots, or LAPACK's own complaint about the NaNs (a ValueError too)
+    with pytest.raises((ValueError, RuntimeError)):  # refused pivots, or the factorisation's own complaint about the NaNs
         randomized_svd_of_product(bad, bad.clone(), 5)
     with pytest.raises(ValueError):
         _hip.lu_row_perm(torch.ones(5, dtype=torch.int32, device="cuda"), 3)

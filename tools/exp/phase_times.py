@@ -58,6 +58,13 @@ def report(name, n_override, tuning=None, mode="dense"):
               f"stages {np.median(T):.0f} (home {np.median(oN):.0f}, min {oN.min():.0f}, max {oN.max():.0f}; seed {np.median(SN):.0f})")
         print(f"        mean Mcycles: seed {seed.mean() / 1e6:.3f}  home {home.mean() / 1e6:.3f}  rest {rest.mean() / 1e6:.3f}  closing {close.mean() / 1e6:.3f}; "
               f"per stage: seed {seed.sum() / max(SN.sum(), 1) / 1e3:.1f}k  home {home.sum() / max(oN.sum(), 1) / 1e3:.1f}k  rest {rest.sum() / rest_stages.sum() / 1e3:.1f}k")
+        slow = np.argsort(-tot)[:4]
+        fast = np.argsort(tot)[:2]
+        for tag, ids in (("slowest", slow), ("fastest", fast)):
+            for i in ids:
+                print(f"        {tag} block {i}: {tot[i] / 1e6:.2f} M; seed {seed[i] / 1e6:.2f} home {home[i] / 1e6:.2f} rest {rest[i] / 1e6:.2f} "
+                      f"closing {close[i] / 1e6:.2f}; per wave entries {b[i, :, 3].mean():.0f} merges {b[i, :, 4].mean():.0f} "
+                      f"candidates {b[i, :, 5].mean():.0f}; wave cycles min/max {b[i, :, 0].min() / 1e6:.2f}/{b[i, :, 0].max() / 1e6:.2f}")
         w = b.reshape(-1, 16)
         print(f"        per wave: entries {w[:, 3].mean():.0f}  merges {w[:, 4].mean():.0f}  candidates {w[:, 5].mean():.0f}  general-path entries {w[:, 9].mean():.0f}  "
               f"candidate-path cycles {w[:, 1].mean() / 1e3:.0f}k of which merges {w[:, 2].mean() / 1e3:.0f}k")

@@ -1,6 +1,6 @@
 #!/bin/bash
-# One bench line + rocprofv3 kernel stats + three counter passes (SQ, FETCH_SIZE, WRITE_SIZE, each a
-# run of its own) for one bench.py workload, condensed into profiles/<tag>_* by summarize_profiles.py.
+# One bench line + rocprofv3 kernel stats + four counter passes (SQ, FETCH_SIZE, WRITE_SIZE, L2 hit / miss
+# and fabric-side read requests, each a run of its own) for one bench.py workload, condensed into profiles/<tag>_* by summarize_profiles.py.
 #   tools/profile_workload.sh <workload> <tag> [bench.py options, e.g. --n 125000]
 # Runs on the GPU box; raw outputs under gpurun_out/<tag>/, summaries under gpurun_out/profiles/<tag>_*
 # (copy those into profiles/ and commit).
@@ -17,6 +17,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/sta
 timeout -s KILL 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq -- python3 $R/bench.py $ONE "$@" > $O/pmc_sq.log 2>&1 || { tail -5 $O/pmc_sq.log; exit 1; }
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py $ONE "$@" > $O/pmc_fetch.log 2>&1 || { tail -5 $O/pmc_fetch.log; exit 1; }
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py $ONE "$@" > $O/pmc_write.log 2>&1 || { tail -5 $O/pmc_write.log; exit 1; }
+timeout -s KILL 200 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum --output-format csv -d $O/pmc_tcc -- python3 $R/bench.py $ONE "$@" > $O/pmc_tcc.log 2>&1 || { tail -5 $O/pmc_tcc.log; exit 1; }
 cd $R
-python3 tools/summarize_profiles.py --stats $O/stats --pmc $O/pmc_sq $O/pmc_fetch $O/pmc_write --bench $O/bench.log --tag $TAG \
+python3 tools/summarize_profiles.py --stats $O/stats --pmc $O/pmc_sq $O/pmc_fetch $O/pmc_write $O/pmc_tcc --bench $O/bench.log --tag $TAG \
     --workload $W --out-dir $R/gpurun_out/profiles "$@"

@@ -55,15 +55,20 @@ def main():
         "kernel": fk, "launches_per_pass": 1, "gpu_cycles_per_xcd": cyc,
         "mfma_busy_frac": v["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024),
         "hbm_bytes_per_launch": hbm,
+        "l2_hit_rate": (v["TCC_HIT_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"])) if "TCC_HIT_sum" in v else None,
+        "l2_read_requests_to_fabric": v.get("TCC_EA0_RDREQ_sum"),
+        "l2_read_requests_marked_dram": v.get("TCC_EA0_RDREQ_DRAM_sum"),
         "note": "one bench.py step (--steps 1 --warmup 0 --no-cpu --no-full) per pass; SQ counters, FETCH_SIZE and "
                 "WRITE_SIZE each in a pass of their own; MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (cycles x 1024 SIMDs); "
-                "HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB",
+                "HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB: what left the XCDs' L2s for the fabric (reads served by the "
+                "Infinity Cache included: no counter of this set tells them from reads of the HBM); L2 hit rate = "
+                "TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum)",
     }
     json.dump(out, open(out_dir / f"{a.tag}_pmc_summary.json", "w"), indent=1)
-    # the file bench.py reads `roofline.traffic` from describes the default workload only
-    traffic_file = out_dir / ("fused_knn_hbm_traffic.json" if a.workload == "c3" and not overridden
-                              else f"{a.tag}_hbm_traffic.json")
-    json.dump({"workload": a.workload, "n_local": a.n_local, "kernel": fk, "source_sha256": bench.kernel_source_hash(),
+    # (bench.py looks through profiles/*_hbm_traffic.json for its workload, shard size, kernel and sources)
+    traffic_file = out_dir / f"{a.tag}_hbm_traffic.json"
+    m_local = a.m or bench.WORKLOADS[a.workload][1]
+    json.dump({"workload": a.workload, "n_local": a.n_local, "m_local": m_local, "kernel": fk, "source_sha256": bench.kernel_source_hash(),
                "FETCH_SIZE_KB": v["FETCH_SIZE"],
                "WRITE_SIZE_KB": v["WRITE_SIZE"], "hbm_bytes_per_launch": hbm,
                "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE doubled as the gfx950 "
