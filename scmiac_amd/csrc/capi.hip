@@ -87,6 +87,9 @@ static KnnWs knn_carve(void* ws, long long n, long long m, int d, const KnnGeome
         w.loc.perm_r = reinterpret_cast<int*>(take(sizeof(int) * (size_t)m));
         w.loc.home = reinterpret_cast<int*>(take(sizeof(int) * 4 * (size_t)g.nqb));
         w.loc.piv_rows = reinterpret_cast<int*>(take(sizeof(int) * 2 * (size_t)g.cells_pad));
+        w.loc.pivT_tmp = reinterpret_cast<float*>(take(sizeof(float) * (size_t)d * g.cells_pad));
+        w.loc.pnorm_tmp = reinterpret_cast<float*>(take(sizeof(float) * (size_t)g.cells_pad));
+        w.loc.pivD = reinterpret_cast<_Float16*>(take(sizeof(_Float16) * (size_t)g.cells * g.cells_pad + 16));
         if (g.prune) {  // pruned search: distances to the pivots, cell radii, per-block stage lists, counters
             w.loc.qpd = reinterpret_cast<float*>(take(sizeof(float) * (size_t)g.cells_pad * (size_t)n));
             w.loc.crad = reinterpret_cast<unsigned*>(take(sizeof(unsigned) * (size_t)g.cells_pad));

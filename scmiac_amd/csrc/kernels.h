@@ -65,7 +65,10 @@ struct LocalityWs {
     int* perm_q;            // [n]: packed query position -> caller's row
     int* perm_r;            // [m]: packed reference row -> caller's row
     int* home;              // [nqb][4]: home window (first stage, stages), own cells inside it (first stage, stages)
-    int* piv_rows;          // [2 cells_pad]: rows of the pivots as chosen, then in chain order
+    int* piv_rows;          // [2 cells_pad]: rows of the pivots as chosen (pruned search), then chain position -> pivot
+    float* pivT_tmp;        // [d][cells_pad], [cells_pad]: the pivots as chosen, before the chain order
+    float* pnorm_tmp;
+    _Float16* pivD;         // [cells][cells_pad]: the pivots' mutual distances
     // pruned search only (NULL otherwise)
     float* qpd;             // [cells_pad][n]: lower bound of dist(query row, pivot)
     unsigned* crad;         // [cells_pad]: float bits, upper bound of max dist(reference row, its pivot)

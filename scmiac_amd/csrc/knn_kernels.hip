@@ -168,66 +168,70 @@ __global__ __launch_bounds__(FPS_NT) void fps_pivots_kernel(const float* __restr
 // at pivot 0, go on to the nearest pivot not yet visited), so that the cells of one cluster of the
 // data -- whose pivots are closer to each other than to any other cluster's -- follow each other.
 // A query block's home window, a run of consecutive packed rows round its own cells, then holds its
-// cluster-mates in the neighbouring cells too.  rows_in: the pivots' rows (NULL: row c * m / C);
-// rows_out[pos] = row of the pos-th pivot of the chain.  One block; C steps of C distances each.
-static constexpr int CHAIN_NT = 1024;
-__global__ __launch_bounds__(CHAIN_NT) void chain_order_kernel(const float* __restrict__ R, long long m, int d, int C,
-                                                               const int* __restrict__ rows_in, int* __restrict__ rows_out,
-                                                               int lds_cells /* pivots cached in LDS: C or 0 */) {
-    extern __shared__ __attribute__((aligned(16))) float chs[];
-    float* pT = chs;                                   // [d][C] when lds_cells == C
-    __shared__ float cur_f[SCMIAC_KNN_MAX_D_INTERNAL];
-    __shared__ float red_v[CHAIN_NT / 64];
-    __shared__ int red_i[CHAIN_NT / 64];
-    __shared__ int cur;
-    __shared__ unsigned char visited[KNN_MAX_CELLS];
-    const int tid = threadIdx.x;
-    auto row_of = [&](int c) { return rows_in != nullptr ? (long long)rows_in[c] : (long long)c * m / C; };
-    for (int c = tid; c < C; c += CHAIN_NT) visited[c] = 0;
-    if (lds_cells == C)
-        for (int e = tid; e < C * d; e += CHAIN_NT) {
-            const int c = e / d, i = e - c * d;
-            pT[i * C + c] = R[row_of(c) * d + i];
-        }
-    if (tid == 0) { cur = 0; visited[0] = 1; rows_out[0] = (int)row_of(0); }
+// cluster-mates in the neighbouring cells too.  Three small kernels: the pivots' mutual distances
+// (half precision is plenty: the order is a heuristic, any order gives the same table), the chain
+// (one wave, the matrix in LDS when it fits: C steps of a few hundred cycles each), and the
+// pivots rewritten in chain order.
+__global__ __launch_bounds__(256) void pivot_dist_kernel(const float* __restrict__ pivT, int d, int C, int Cpad,
+                                                         _Float16* __restrict__ D /* [C][Cpad] */) {
+    __shared__ float mine[SCMIAC_KNN_MAX_D_INTERNAL];
+    const int c = blockIdx.x;
+    for (int i = threadIdx.x; i < d; i += blockDim.x) mine[i] = pivT[(long long)i * Cpad + c];
     __syncthreads();
+    for (int t = threadIdx.x; t < Cpad; t += blockDim.x) {
+        float acc = 0.0f;
+        if (t < C)
+            for (int i = 0; i < d; ++i) { const float v = pivT[(long long)i * Cpad + t] - mine[i]; acc = __fmaf_rn(v, v, acc); }
+        float dist = sqrtf(acc);
+        if (!(dist < 60000.0f)) dist = 60000.0f;  // (half precision's range; NaN pivots come last)
+        D[(long long)c * Cpad + t] = (_Float16)dist;
+    }
+}
+
+static constexpr int CHAIN_LDS_CELLS = 272;  // largest C whose matrix (C x Cpad halves) the chain keeps in LDS
+__global__ __launch_bounds__(64) void chain_order_kernel(const _Float16* __restrict__ D, int C, int Cpad,
+                                                         int* __restrict__ chain /* [C]: pos -> pivot */, int in_lds) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 dm[];
+    const int lane = threadIdx.x;
+    if (in_lds) {
+        const uint4* src = reinterpret_cast<const uint4*>(D);
+        uint4* dst = reinterpret_cast<uint4*>(dm);
+        const int n16 = (int)(((long long)C * Cpad * 2 + 15) / 16);
+        for (int i = lane; i < n16; i += 64) dst[i] = src[i];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    // lane l owns pivots l, l + 64, ...: bit b of `seen` = pivot l + 64 b visited
+    unsigned seen = 0u;
+    int cur = 0;
+    if (lane == 0) { seen = 1u; chain[0] = 0; }
     for (int step = 1; step < C; ++step) {
-        const long long crow = row_of(cur);
-        for (int i = tid; i < d; i += CHAIN_NT) cur_f[i] = R[crow * d + i];
-        __syncthreads();
-        float best = __builtin_inff();
-        int besti = -1;
-        for (int c = tid; c < C; c += CHAIN_NT) {
-            if (visited[c]) continue;
-            float acc = 0.0f;
-            if (lds_cells == C) {
-                for (int i = 0; i < d; ++i) { const float t = pT[i * C + c] - cur_f[i]; acc = __fmaf_rn(t, t, acc); }
-            } else {
-                const float* row = R + row_of(c) * d;
-                for (int i = 0; i < d; ++i) { const float t = row[i] - cur_f[i]; acc = __fmaf_rn(t, t, acc); }
-            }
-            if (!(acc == acc)) acc = 3.0e38f;  // (a pivot with NaNs is visited last)
-            if (acc < best) { best = acc; besti = c; }
+        const _Float16* row = (in_lds ? dm : D) + (long long)cur * Cpad;
+        float best = 3.0e38f;
+        int besti = 0x7fffffff;
+        for (int b = 0, c = lane; c < C; ++b, c += 64) {
+            if ((seen >> b) & 1u) continue;
+            const float v = (float)row[c];
+            if (v < best) { best = v; besti = c; }   // (ascending c: the lowest pivot number among equals)
         }
         for (int off = 32; off; off >>= 1) {
             const float ov = __shfl_xor(best, off);
             const int oi = __shfl_xor(besti, off);
-            if (oi >= 0 && (besti < 0 || ov < best || (ov == best && oi < besti))) { best = ov; besti = oi; }
+            if (ov < best || (ov == best && oi < besti)) { best = ov; besti = oi; }
         }
-        if ((tid & 63) == 0) { red_v[tid >> 6] = best; red_i[tid >> 6] = besti; }
-        __syncthreads();
-        if (tid == 0) {
-            for (int w = 1; w < CHAIN_NT / 64; ++w) {
-                const float ov = red_v[w];
-                const int oi = red_i[w];
-                if (oi >= 0 && (besti < 0 || ov < best || (ov == best && oi < besti))) { best = ov; besti = oi; }
-            }
-            cur = besti;             // (step < C: at least one pivot is unvisited)
-            visited[besti] = 1;
-            rows_out[step] = (int)row_of(besti);
-        }
-        __syncthreads();
+        cur = besti;  // (step < C: some pivot is unvisited, so besti is a pivot)
+        if ((cur & 63) == lane) seen |= 1u << (cur >> 6);
+        if (lane == 0) chain[step] = cur;
     }
+}
+
+// the pivots in chain order: pivT2[i][pos] = pivT[i][chain[pos]], likewise the norms
+__global__ void permute_pivots_kernel(const float* __restrict__ pivT, const float* __restrict__ pnorm, int d, int C, int Cpad,
+                                      const int* __restrict__ chain, float* __restrict__ pivT2, float* __restrict__ pnorm2) {
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= Cpad) return;
+    const int c = pos < C ? chain[pos] : pos;
+    for (int i = 0; i < d; ++i) pivT2[(long long)i * Cpad + pos] = pivT[(long long)i * Cpad + c];
+    pnorm2[pos] = pnorm[c];
 }
 
 // pivT[i][c] = feature i of pivot c (= row (c * m) / C of R, or row piv_rows[c]), pnorm[c] = |pivot c|^2
@@ -413,7 +417,7 @@ __global__ __launch_bounds__(256) void cell_scatter_kernel(const cell_t* __restr
 // queries' cluster.  (Own cells longer than the window: the window is their head.)
 __global__ void home_stages_kernel(const cell_t* __restrict__ qcell, const int* __restrict__ perm_q,
                                    long long n, int qpb, int nqb, const int* __restrict__ rcell_start, int RT,
-                                   long long m_pad, int max_stages, int* __restrict__ home) {
+                                   long long m_pad, int max_stages, int widen, int* __restrict__ home) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nqb) return;
     const long long first = (long long)b * qpb;
@@ -429,7 +433,7 @@ __global__ void home_stages_kernel(const cell_t* __restrict__ qcell, const int* 
         if (s1 > s0 + max_stages) s1 = s0 + max_stages;
         if (s1 > s0) {
             o0 = (int)s0; on = (int)(s1 - s0);
-            long long spare = max_stages - (s1 - s0);   // stages the window may add round the own cells
+            long long spare = widen ? max_stages - (s1 - s0) : 0;  // stages the window may add round the own cells
             long long a = s0 - spare / 2, z = s1 + (spare - spare / 2);
             if (a < 0) { z -= a; a = 0; }
             if (z > total) { a -= z - total; z = total; }
@@ -837,7 +841,13 @@ KnnGeometry knn_geometry(long long n, long long m, int d, int k, int splits, int
     // chunk refills its shortlist from scratch and adds a list per query to the refine
     // pass.  (S, St) minimise a cycle model of the fused kernel fitted on MI355X.
     int S = 1, St = 1, qb0 = g.nqb;
-    if (splits > 0) {
+    // A pruned search streams a query block's own cluster and little else: cutting its reference
+    // range into chunks would buy no balance and cost every chunk but one the sight of its
+    // queries' own cells (the thresholds the reach test lives on).  One block per query block.
+    const bool want_prune = mode == 1 && g.cells > 0 && fused_pruned_compiled(g);
+    if (want_prune && splits <= 0) {
+        // (S = St = 1)
+    } else if (splits > 0) {
         S = splits;
         if (S > rows_rt) S = (int)(rows_rt > 0 ? rows_rt : 1);
     } else {
@@ -907,7 +917,7 @@ KnnGeometry knn_geometry(long long n, long long m, int d, int k, int splits, int
     // pruned search: where the partition applies, the variant has a pruned instantiation and a
     // block's stage list fits 16-bit stage numbers; the dense search otherwise
     const long long longest = g.chunk_rows > t.chunk_rows ? g.chunk_rows : t.chunk_rows;
-    g.prune = (mode == 1 && g.cells > 0 && longest / g.RT < 65535 && fused_pruned_compiled(g)) ? 1 : 0;
+    g.prune = (want_prune && longest / g.RT < 65535) ? 1 : 0;
     return g;
 }
 
@@ -966,24 +976,29 @@ hipError_t launch_locality(const float* Q, long long n, const float* R, long lon
         hipLaunchKernelGGL(fps_pivots_kernel, dim3(1), dim3(FPS_NT), 0, stream, R, m, d, g.cells, w.piv_rows);
         piv_rows = w.piv_rows;
     }
-    {   // the cells in chain order (the pivots cached in LDS when they fit)
-        const size_t lds = sizeof(float) * (size_t)g.cells * d;
-        const bool fits = lds <= 96 * 1024;
+    // the pivots as chosen (scratch copy), their mutual distances, the chain, the pivots in chain order
+    const unsigned pgrid = (unsigned)((g.cells_pad + 63) / 64);
+    hipLaunchKernelGGL(pivots_kernel, dim3(pgrid), dim3(64), 0, stream, R, m, d, g.cells, g.cells_pad, w.pivT_tmp, w.pnorm_tmp,
+                       piv_rows);
+    hipLaunchKernelGGL(pivot_dist_kernel, dim3((unsigned)g.cells), dim3(256), 0, stream, w.pivT_tmp, d, g.cells, g.cells_pad,
+                       w.pivD);
+    {
+        const bool in_lds = g.cells <= CHAIN_LDS_CELLS;
+        const size_t lds = in_lds ? ((sizeof(_Float16) * (size_t)g.cells * g.cells_pad + 15) & ~(size_t)15) : 0;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_order_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(fits ? lds : 0));
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(chain_order_kernel, dim3(1), dim3(CHAIN_NT), fits ? lds : 0, stream, R, m, d, g.cells, piv_rows,
-                           w.piv_rows + g.cells_pad, fits ? g.cells : 0);
-        piv_rows = w.piv_rows + g.cells_pad;
+        hipLaunchKernelGGL(chain_order_kernel, dim3(1), dim3(64), lds, stream, w.pivD, g.cells, g.cells_pad, w.piv_rows + g.cells_pad,
+                           in_lds ? 1 : 0);
     }
-    hipLaunchKernelGGL(pivots_kernel, dim3((unsigned)((g.cells_pad + 63) / 64)), dim3(64), 0, stream, R, m, d, g.cells,
-                       g.cells_pad, w.pivT, w.pnorm, piv_rows);
+    hipLaunchKernelGGL(permute_pivots_kernel, dim3(pgrid), dim3(64), 0, stream, w.pivT_tmp, w.pnorm_tmp, d, g.cells, g.cells_pad,
+                       w.piv_rows + g.cells_pad, w.pivT, w.pnorm);
     hipError_t e = launch_cells(R, m, d, g, w.pivT, w.pnorm, w.cell_r, w.hist_r, w.cstart_r, w.perm_r, nullptr, w.crad, stream);
     if (e != hipSuccess) return e;
     e = launch_cells(Q, n, d, g, w.pivT, w.pnorm, w.cell_q, w.hist_q, w.cstart_q, w.perm_q, w.qpd, nullptr, stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(home_stages_kernel, dim3((unsigned)((g.nqb + 63) / 64)), dim3(64), 0, stream, w.cell_q, w.perm_q,
-                       n, g.qpb, g.nqb, w.cstart_r, g.RT, g.m_pad, g.home_max, w.home);
+                       n, g.qpb, g.nqb, w.cstart_r, g.RT, g.m_pad, g.home_max, g.prune ? 0 : 1, w.home);
     return hipGetLastError();
 }
 

@@ -64,7 +64,8 @@ def report(name, n_override, tuning=None, mode="dense"):
             for i in ids:
                 print(f"        {tag} block {i}: {tot[i] / 1e6:.2f} M; seed {seed[i] / 1e6:.2f} home {home[i] / 1e6:.2f} rest {rest[i] / 1e6:.2f} "
                       f"closing {close[i] / 1e6:.2f}; per wave entries {b[i, :, 3].mean():.0f} merges {b[i, :, 4].mean():.0f} "
-                      f"candidates {b[i, :, 5].mean():.0f}; wave cycles min/max {b[i, :, 0].min() / 1e6:.2f}/{b[i, :, 0].max() / 1e6:.2f}")
+                      f"candidates {b[i, :, 5].mean():.0f}; stages streamed {T[i]:.0f} (home {oN[i]:.0f}, seed {SN[i]:.0f}); "
+                      f"candidates per wave min/max {b[i, :, 5].min():.0f}/{b[i, :, 5].max():.0f}")
         w = b.reshape(-1, 16)
         print(f"        per wave: entries {w[:, 3].mean():.0f}  merges {w[:, 4].mean():.0f}  candidates {w[:, 5].mean():.0f}  general-path entries {w[:, 9].mean():.0f}  "
               f"candidate-path cycles {w[:, 1].mean() / 1e3:.0f}k of which merges {w[:, 2].mean() / 1e3:.0f}k")
