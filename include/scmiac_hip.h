@@ -217,8 +217,9 @@ SCMIAC_API int scmiac_anchor_filter(const int64_t *pairs, const int64_t *n_pairs
  *                  both sets by nearest pivot first (same result, A/B timing aid)
  *   home_rows, seed_rows, cell_rows  > 0: override how many of its queries' home rows a
  *                  block streams first (8192), how many of them the seed pass looks at
- *                  (3072) and the reference rows per pivot cell aimed at (1024; the library's
- *                  own choice stops at 248 cells, an explicit value may ask for up to 2048)
+ *                  (6144) and the reference rows per pivot cell aimed at (1024; the library's
+ *                  own choice stops at 1024 cells -- 248 for a pruned search --, an explicit value
+ *                  may ask for up to 2048)
  * Thread-safe; every later call of the library reads the knobs once, at its start.
  */
 SCMIAC_API int scmiac_knn_set_tuning(int slots, int tail_min_rows, int no_tail, int ablate, int diag, int nw,

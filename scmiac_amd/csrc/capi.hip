@@ -86,10 +86,11 @@ static KnnWs knn_carve(void* ws, long long n, long long m, int d, const KnnGeome
         w.loc.perm_q = reinterpret_cast<int*>(take(sizeof(int) * (size_t)n));
         w.loc.perm_r = reinterpret_cast<int*>(take(sizeof(int) * (size_t)m));
         w.loc.home = reinterpret_cast<int*>(take(sizeof(int) * 4 * (size_t)g.nqb));
-        w.loc.piv_rows = reinterpret_cast<int*>(take(sizeof(int) * 2 * (size_t)g.cells_pad));
+        w.loc.piv_rows = reinterpret_cast<int*>(take(sizeof(int) * 4 * (size_t)g.cells_pad));
         w.loc.pivT_tmp = reinterpret_cast<float*>(take(sizeof(float) * (size_t)d * g.cells_pad));
         w.loc.pnorm_tmp = reinterpret_cast<float*>(take(sizeof(float) * (size_t)g.cells_pad));
-        w.loc.pivD = reinterpret_cast<_Float16*>(take(sizeof(_Float16) * (size_t)g.cells * g.cells_pad + 16));
+        w.loc.pivD = reinterpret_cast<_Float16*>(take(sizeof(_Float16) * 256 * 256 + 16));
+        w.loc.pivRM = reinterpret_cast<float*>(take(sizeof(float) * (size_t)d * g.cells_pad));
         if (g.prune) {  // pruned search: distances to the pivots, cell radii, per-block stage lists, counters
             w.loc.qpd = reinterpret_cast<float*>(take(sizeof(float) * (size_t)g.cells_pad * (size_t)n));
             w.loc.crad = reinterpret_cast<unsigned*>(take(sizeof(unsigned) * (size_t)g.cells_pad));
@@ -197,7 +198,7 @@ int scmiac_knn_kernel_name(int64_t n, int64_t m, int d, int k, int splits, int m
     const FusedTuning tn = knn_get_tuning();
     KnnGeometry g = knn_geometry(n, m, d, k, splits, mode, tn);
     if (g.D2 < 0) return fail(SCMIAC_ERR_ARG, "unsupported feature dimension %d", d);
-    const int kind = (tn.diag || (tn.ablate & 63)) ? 1 : (g.prune ? 2 : 0);
+    const int kind = (tn.diag || (tn.ablate & (63 | 128))) ? 1 : (g.prune ? 2 : 0);
     snprintf(buf, buf_bytes, "fused_knn_kernel<%d, %d, %d, %d, %s, %d>", g.D2, g.nw, g.RT, g.pcap,
              g.gp ? "true" : "false", kind);
     return SCMIAC_OK;

@@ -63,6 +63,7 @@ __device__ __forceinline__ float flush_query(unsigned c0, unsigned c1, const uin
 // what the stage loop does with a finished subtile: smallest score against the threshold
 #define SCMIAC_TEST_PREV(PRV_)                                                                      \
     do {                                                                                            \
+        if (DIAG_ && (ablate & 128)) break; /* diagnostic: the stream without the per-subtile test */ \
             /* smallest of the 16 scores as a depth-3 tree: a wave waits its turn for every */      \
             /* instruction that depends on the one before: depth costs, not count           */      \
             const float m0_ = min3_after_mfma(accs[PRV_][0], accs[PRV_][1], accs[PRV_][2]);         \

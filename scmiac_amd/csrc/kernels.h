@@ -65,10 +65,11 @@ struct LocalityWs {
     int* perm_q;            // [n]: packed query position -> caller's row
     int* perm_r;            // [m]: packed reference row -> caller's row
     int* home;              // [nqb][4]: home window (first stage, stages), own cells inside it (first stage, stages)
-    int* piv_rows;          // [2 cells_pad]: rows of the pivots as chosen (pruned search), then chain position -> pivot
+    int* piv_rows;          // [4 cells_pad]: rows of the pivots as chosen (pruned search); scratch of the chain order
     float* pivT_tmp;        // [d][cells_pad], [cells_pad]: the pivots as chosen, before the chain order
     float* pnorm_tmp;
-    _Float16* pivD;         // [cells][cells_pad]: the pivots' mutual distances
+    _Float16* pivD;         // [256][256]: mutual distances of the chain's lead pivots
+    float* pivRM;           // [cells_pad][d]: the pivots in chain order, one per row (A operand of the MFMA assignment)
     // pruned search only (NULL otherwise)
     float* qpd;             // [cells_pad][n]: lower bound of dist(query row, pivot)
     unsigned* crad;         // [cells_pad]: float bits, upper bound of max dist(reference row, its pivot)
@@ -86,7 +87,7 @@ struct FusedTuning {
     int diag;           // 1: per-wave cycle counters into the workspace
     int no_locality;    // 1: stream the references in the caller's order (no pivot partition)
     int home_rows;      // > 0: most home rows a query block streams first (default 8192)
-    int seed_rows;      // > 0: home rows the seed pass looks at (default 3072)
+    int seed_rows;      // > 0: home rows the seed pass looks at (default 6144)
     int cell_rows;      // > 0: reference rows per pivot cell aimed at (default 1024)
     int has_variant;    // 1: use (nw, rt, pcap, gp) where that combination is compiled
     int nw, rt, pcap, gp;

@@ -168,69 +168,115 @@ __global__ __launch_bounds__(FPS_NT) void fps_pivots_kernel(const float* __restr
 // at pivot 0, go on to the nearest pivot not yet visited), so that the cells of one cluster of the
 // data -- whose pivots are closer to each other than to any other cluster's -- follow each other.
 // A query block's home window, a run of consecutive packed rows round its own cells, then holds its
-// cluster-mates in the neighbouring cells too.  Three small kernels: the pivots' mutual distances
-// (half precision is plenty: the order is a heuristic, any order gives the same table), the chain
-// (one wave, the matrix in LDS when it fits: C steps of a few hundred cycles each), and the
-// pivots rewritten in chain order.
-__global__ __launch_bounds__(256) void pivot_dist_kernel(const float* __restrict__ pivT, int d, int C, int Cpad,
-                                                         _Float16* __restrict__ D /* [C][Cpad] */) {
+// cluster-mates in the neighbouring cells too.  The chain itself is serial, so it runs over at most
+// CHAIN_MAX "lead" pivots (every stride-th one), one wave, their mutual distances in LDS (half
+// precision is plenty: the order is a heuristic, any order gives the same table): a few hundred
+// cycles per step.  Every other pivot follows the lead it is nearest to.
+static constexpr int CHAIN_MAX = 256;
+__global__ __launch_bounds__(256) void pivot_dist_kernel(const float* __restrict__ pivT, int d, int C, int Cpad, int stride,
+                                                         int S, _Float16* __restrict__ D /* [S][S] */,
+                                                         int* __restrict__ near /* [C]: nearest lead of every pivot */) {
     __shared__ float mine[SCMIAC_KNN_MAX_D_INTERNAL];
-    const int c = blockIdx.x;
-    for (int i = threadIdx.x; i < d; i += blockDim.x) mine[i] = pivT[(long long)i * Cpad + c];
+    __shared__ float red_v[4];
+    __shared__ int red_i[4];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < d; i += blockDim.x) mine[i] = pivT[(long long)i * Cpad + c];
     __syncthreads();
-    for (int t = threadIdx.x; t < Cpad; t += blockDim.x) {
+    const bool lead = (c % stride == 0) && (c / stride < S);
+    float best = 3.0e38f;
+    int besti = 0x7fffffff;
+    if (tid < S) {  // S <= 256 = blockDim
+        const int t = tid * stride;
         float acc = 0.0f;
-        if (t < C)
-            for (int i = 0; i < d; ++i) { const float v = pivT[(long long)i * Cpad + t] - mine[i]; acc = __fmaf_rn(v, v, acc); }
+        for (int i = 0; i < d; ++i) { const float v = pivT[(long long)i * Cpad + t] - mine[i]; acc = __fmaf_rn(v, v, acc); }
         float dist = sqrtf(acc);
         if (!(dist < 60000.0f)) dist = 60000.0f;  // (half precision's range; NaN pivots come last)
-        D[(long long)c * Cpad + t] = (_Float16)dist;
+        if (lead) D[(long long)(c / stride) * S + tid] = (_Float16)dist;
+        best = dist; besti = tid;
+    }
+    for (int off = 32; off; off >>= 1) {
+        const float ov = __shfl_xor(best, off);
+        const int oi = __shfl_xor(besti, off);
+        if (ov < best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+    }
+    if ((tid & 63) == 0) { red_v[tid >> 6] = best; red_i[tid >> 6] = besti; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (red_v[w] < best || (red_v[w] == best && red_i[w] < besti)) { best = red_v[w]; besti = red_i[w]; }
+        near[c] = lead ? c / stride : besti;
     }
 }
 
-static constexpr int CHAIN_LDS_CELLS = 272;  // largest C whose matrix (C x Cpad halves) the chain keeps in LDS
-__global__ __launch_bounds__(64) void chain_order_kernel(const _Float16* __restrict__ D, int C, int Cpad,
-                                                         int* __restrict__ chain /* [C]: pos -> pivot */, int in_lds) {
-    extern __shared__ __attribute__((aligned(16))) _Float16 dm[];
+// chain over the S leads (one wave); chain[pos] = lead
+__global__ __launch_bounds__(64) void chain_order_kernel(const _Float16* __restrict__ D, int S, int* __restrict__ chain) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 dm[];  // [S][S]
     const int lane = threadIdx.x;
-    if (in_lds) {
-        const uint4* src = reinterpret_cast<const uint4*>(D);
-        uint4* dst = reinterpret_cast<uint4*>(dm);
-        const int n16 = (int)(((long long)C * Cpad * 2 + 15) / 16);
-        for (int i = lane; i < n16; i += 64) dst[i] = src[i];
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    }
-    // lane l owns pivots l, l + 64, ...: bit b of `seen` = pivot l + 64 b visited
+    for (int i = lane; i < S * S; i += 64) dm[i] = D[i];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // lane l owns leads l, l + 64, ...: bit b of `seen` = lead l + 64 b visited
     unsigned seen = 0u;
     int cur = 0;
     if (lane == 0) { seen = 1u; chain[0] = 0; }
-    for (int step = 1; step < C; ++step) {
-        const _Float16* row = (in_lds ? dm : D) + (long long)cur * Cpad;
+    for (int step = 1; step < S; ++step) {
+        const _Float16* row = dm + cur * S;
         float best = 3.0e38f;
         int besti = 0x7fffffff;
-        for (int b = 0, c = lane; c < C; ++b, c += 64) {
-            if ((seen >> b) & 1u) continue;
+        for (int b = 0, c = lane; c < S; ++b, c += 64) {
             const float v = (float)row[c];
-            if (v < best) { best = v; besti = c; }   // (ascending c: the lowest pivot number among equals)
+            if (!((seen >> b) & 1u) && v < best) { best = v; besti = c; }   // (ascending c: the lowest number among equals)
         }
         for (int off = 32; off; off >>= 1) {
             const float ov = __shfl_xor(best, off);
             const int oi = __shfl_xor(besti, off);
             if (ov < best || (ov == best && oi < besti)) { best = ov; besti = oi; }
         }
-        cur = besti;  // (step < C: some pivot is unvisited, so besti is a pivot)
+        cur = besti;  // (step < S: some lead is unvisited, so besti is one)
         if ((cur & 63) == lane) seen |= 1u << (cur >> 6);
         if (lane == 0) chain[step] = cur;
     }
 }
 
+// order[pos] = pivot: the leads in chain order, each followed by the pivots nearest to it (ascending)
+__global__ __launch_bounds__(1024) void chain_expand_kernel(const int* __restrict__ chain, const int* __restrict__ near, int C,
+                                                            int S, int* __restrict__ order) {
+    __shared__ int rank[CHAIN_MAX], start[CHAIN_MAX + 1], cnt[CHAIN_MAX];
+    __shared__ unsigned short nr[KNN_MAX_CELLS];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < S; i += 1024) { rank[chain[i]] = i; cnt[i] = 0; }
+    __syncthreads();
+    for (int c = tid; c < C; c += 1024) {
+        const int r = rank[near[c]];
+        nr[c] = (unsigned short)r;
+        atomicAdd(&cnt[r], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0;
+        for (int i = 0; i < S; ++i) { start[i] = acc; acc += cnt[i]; }
+        start[S] = acc;
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 1024) {
+        const int r = nr[c];
+        int before = 0;
+        for (int o = 0; o < c; ++o) before += (nr[o] == r) ? 1 : 0;
+        order[start[r] + before] = c;
+    }
+}
+
 // the pivots in chain order: pivT2[i][pos] = pivT[i][chain[pos]], likewise the norms
 __global__ void permute_pivots_kernel(const float* __restrict__ pivT, const float* __restrict__ pnorm, int d, int C, int Cpad,
-                                      const int* __restrict__ chain, float* __restrict__ pivT2, float* __restrict__ pnorm2) {
+                                      const int* __restrict__ chain, float* __restrict__ pivT2, float* __restrict__ pnorm2,
+                                      float* __restrict__ pivRM /* [Cpad][d]: the same, one pivot per row */) {
     const int pos = blockIdx.x * blockDim.x + threadIdx.x;
     if (pos >= Cpad) return;
     const int c = pos < C ? chain[pos] : pos;
-    for (int i = 0; i < d; ++i) pivT2[(long long)i * Cpad + pos] = pivT[(long long)i * Cpad + c];
+    for (int i = 0; i < d; ++i) {
+        const float v = pivT[(long long)i * Cpad + c];
+        pivT2[(long long)i * Cpad + pos] = v;
+        pivRM[(long long)pos * d + i] = v;
+    }
     pnorm2[pos] = pnorm[c];
 }
 
@@ -354,6 +400,116 @@ __global__ __launch_bounds__(CELL_NT) void assign_cells_kernel(const float* __re
     }
     __syncthreads();
     for (int i = tid; i < C; i += CELL_NT) blockhist[(long long)blockIdx.x * C + i] = hist[i];
+}
+
+// The same assignment on the matrix cores, for the dense search (no bounds to write out): the
+// scores |p|^2 - 2 x.p of 32 rows against 32 pivots are one chain of fp32 MFMAs (32x32x2), the
+// rows' features the B operand in registers, a tile of pivots the A operand out of LDS -- lane
+// (j, hh) ends up with 16 scores of ITS row j, so the running minimum needs no cross-lane traffic
+// until the two lane halves meet at the end.  Which pivot a minimum belongs to rides in the low
+// four mantissa bits of the score (the register number) and in the number of the tile.  The
+// perturbation (16 ulp) can prefer one of two nearly equidistant pivots over the other; any
+// assignment gives the same table.  WAVES x GROUPS x 32 rows per block.
+template <int D2MAX, int GROUPS, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void assign_cells_mfma_kernel(const float* __restrict__ X, long long n, int d,
+                                                                       const float* __restrict__ pivRM /* [C][d] */,
+                                                                       const float* __restrict__ pnorm, int C,
+                                                                       cell_t* __restrict__ cell,
+                                                                       int* __restrict__ blockhist) {
+    constexpr int NT = WAVES * 64, RB = WAVES * GROUPS * 32;
+    const int D2 = (d + 1) / 2, D2P = (D2 + 3) & ~3;
+    const int LSP = 2 * D2P + ((((2 * D2P) / 4) % 2 == 0) ? 4 : 8);  // odd number of 16-byte slots per pivot row
+    extern __shared__ __attribute__((aligned(16))) float asm_[];
+    float* pt = asm_;                               // [32][LSP]: a tile of pivots, lane-half-major features
+    float* pnl = pt + 32 * LSP;                     // [32]
+    int* hist = reinterpret_cast<int*>(pnl + 32);   // [C]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, hh = lane >> 5;
+    const long long row0 = (long long)blockIdx.x * RB;
+    for (int i = tid; i < C; i += NT) hist[i] = 0;
+    // B operand: -2 x features hh * D2 + s of this lane's row, per group
+    float qf[GROUPS][D2MAX];
+#pragma unroll
+    for (int g = 0; g < GROUPS; ++g) {
+        const long long row = row0 + (long long)(wave * GROUPS + g) * 32 + j;
+#pragma unroll
+        for (int sidx = 0; sidx < D2MAX; ++sidx) {
+            const int f = hh * D2 + sidx;
+            qf[g][sidx] = (row < n && sidx < D2 && f < d) ? -2.0f * X[row * d + f] : 0.0f;
+        }
+    }
+    float best[GROUPS];
+    int best_tile[GROUPS];
+#pragma unroll
+    for (int g = 0; g < GROUPS; ++g) { best[g] = __builtin_inff(); best_tile[g] = 0; }
+    const int tiles = (C + 31) / 32;
+    for (int t = 0; t < tiles; ++t) {
+        __syncthreads();  // everyone is done with the previous tile
+        {   // NT / 32 threads per pivot row, no divisions in the loop
+            constexpr int TPR = NT / 32;
+            const int pj = tid / TPR, pc = t * 32 + pj;
+            const float* src = pivRM + (long long)pc * d;
+            for (int c = tid % TPR; c < 2 * D2P; c += TPR) {
+                const int ph = c >= D2P ? 1 : 0, ps = c - ph * D2P;
+                const int f = ph * D2 + ps;
+                pt[pj * LSP + c] = (ps < D2 && f < d && pc < C) ? src[f] : 0.0f;
+            }
+        }
+        if (tid < 32) pnl[tid] = (t * 32 + tid < C) ? pnorm[t * 32 + tid] : 3.0e38f;
+        __syncthreads();
+        f32x16 acc[GROUPS];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const float4 nv = lds_read_b128(pnl + 8 * q4 + 4 * hh);
+#pragma unroll
+            for (int g = 0; g < GROUPS; ++g) {
+                acc[g][4 * q4 + 0] = nv.x; acc[g][4 * q4 + 1] = nv.y; acc[g][4 * q4 + 2] = nv.z; acc[g][4 * q4 + 3] = nv.w;
+            }
+        }
+#pragma unroll
+        for (int s4 = 0; s4 < D2MAX / 4; ++s4) {
+            if (4 * s4 < D2) {  // (wave-uniform)
+                const float4 a4 = lds_read_b128(pt + j * LSP + hh * D2P + 4 * s4);
+                const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (4 * s4 + e < D2) {
+#pragma unroll
+                        for (int g = 0; g < GROUPS; ++g)
+                            acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], qf[g][4 * s4 + e], acc[g], 0, 0, 0);
+                    }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g) {
+            float key[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) key[r] = score_key(acc[g][r], r);
+            const float a0 = fminf(fminf(key[0], key[1]), fminf(key[2], key[3]));
+            const float a1 = fminf(fminf(key[4], key[5]), fminf(key[6], key[7]));
+            const float a2 = fminf(fminf(key[8], key[9]), fminf(key[10], key[11]));
+            const float a3 = fminf(fminf(key[12], key[13]), fminf(key[14], key[15]));
+            const float kb = fminf(fminf(a0, a1), fminf(a2, a3));
+            if (kb < best[g]) { best[g] = kb; best_tile[g] = t; }   // strict: the earlier tile among equals
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < GROUPS; ++g) {
+        const unsigned r = __float_as_uint(best[g]) & 15u;
+        int pc = best_tile[g] * 32 + (int)((r & 3u) + 8u * (r >> 2)) + 4 * hh;
+        float b = best[g];
+        const float ob = __shfl_xor(b, 32);
+        const int oc = __shfl_xor(pc, 32);
+        if (ob < b || (ob == b && oc < pc)) { b = ob; pc = oc; }
+        const long long row = row0 + (long long)(wave * GROUPS + g) * 32 + j;
+        if (hh == 0 && row < n) {
+            if (pc >= C || !(b < __builtin_inff())) pc = 0;  // NaN rows stay in cell 0
+            cell[row] = (cell_t)pc;
+            atomicAdd(&hist[pc], 1);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < C; i += NT) blockhist[(long long)blockIdx.x * C + i] = hist[i];
 }
 
 // blockhist[b][c] -> rows of cell c in blocks before b (one block per cell scans its column);
@@ -811,16 +967,18 @@ KnnGeometry knn_geometry(long long n, long long m, int d, int k, int splits, int
     g.cells = 0; g.cells_pad = 0; g.home_max = 0; g.seed_stages = 0;
     if (!tn.no_locality && m >= 16384 && n >= 2048) {
         long long c = m / (tn.cell_rows > 0 ? tn.cell_rows : 1024);
-        // (assigning a row costs one distance per cell: the library's own choice stops at 248 cells,
-        // an explicit cell size may ask for up to KNN_MAX_CELLS)
-        const long long cmax = tn.cell_rows > 0 ? KNN_MAX_CELLS : 248;
+        // (assigning a row costs one distance per cell -- on the matrix cores for the dense search,
+        // on the vector units with a bound per (query, cell) written out for the pruned one: the
+        // library's own choice stops at 1024 and 248 cells, an explicit cell size may ask for up to
+        // KNN_MAX_CELLS)
+        const long long cmax = tn.cell_rows > 0 ? KNN_MAX_CELLS : (mode == 1 ? 248 : 1024);
         c = c < 8 ? 8 : (c > cmax ? cmax : c);
         g.cells = (int)c;
         g.cells_pad = (g.cells + 7) & ~7;
         // a block streams at most this many home stages first ...
         g.home_max = ((tn.home_rows > 0 ? tn.home_rows : 8192) + g.RT - 1) / g.RT;
         // ... and looks at this many of them for its thresholds
-        g.seed_stages = ((tn.seed_rows > 0 ? tn.seed_rows : 3072) + g.RT - 1) / g.RT;
+        g.seed_stages = ((tn.seed_rows > 0 ? tn.seed_rows : 6144) + g.RT - 1) / g.RT;
     }
     g.qpb = g.nw * 32;
     g.n_pad = ((n + g.qpb - 1) / g.qpb) * g.qpb;
@@ -947,15 +1105,35 @@ static hipError_t launch_assign(const float* X, long long n, int d, int C, int C
     return hipGetLastError();
 }
 
+template <int D2MAX, int GROUPS, int WAVES>
+static hipError_t launch_assign_mfma(const float* X, long long n, int d, int C, const float* pivRM, const float* pnorm,
+                                     cell_t* cell, int* blockhist, hipStream_t stream) {
+    constexpr int RB = WAVES * GROUPS * 32;
+    const int D2P = (((d + 1) / 2) + 3) & ~3;
+    const int LSP = 2 * D2P + ((((2 * D2P) / 4) % 2 == 0) ? 4 : 8);
+    const size_t lds = sizeof(float) * (32 * (size_t)LSP + 32) + sizeof(int) * (size_t)C;
+    const int nblk = (int)((n + RB - 1) / RB);
+    hipLaunchKernelGGL((assign_cells_mfma_kernel<D2MAX, GROUPS, WAVES>), dim3((unsigned)nblk), dim3(WAVES * 64), lds, stream, X, n,
+                       d, pivRM, pnorm, C, cell, blockhist);
+    return hipGetLastError();
+}
+
 static hipError_t launch_cells(const float* X, long long n, int d, const KnnGeometry& g, const float* pivT,
-                               const float* pnorm, cell_t* cell, int* blockhist, int* cell_start, int* perm,
-                               float* qpd, unsigned* crad, hipStream_t stream) {
+                               const float* pivRM, const float* pnorm, cell_t* cell, int* blockhist, int* cell_start,
+                               int* perm, float* qpd, unsigned* crad, hipStream_t stream) {
     const int C = g.cells, Cpad = g.cells_pad;
     const int rb = cell_rows_per_block(d);
     const int nblk = (int)((n + rb - 1) / rb);
-    hipError_t e = rb == 256 ? launch_assign<256>(X, n, d, C, Cpad, pivT, pnorm, cell, blockhist, qpd, crad, stream)
-                 : rb == 128 ? launch_assign<128>(X, n, d, C, Cpad, pivT, pnorm, cell, blockhist, qpd, crad, stream)
-                             : launch_assign<64>(X, n, d, C, Cpad, pivT, pnorm, cell, blockhist, qpd, crad, stream);
+    hipError_t e;
+    if (qpd == nullptr && crad == nullptr) {  // no bounds wanted: the matrix cores (same rows per block)
+        e = rb == 256 ? launch_assign_mfma<32, 2, 4>(X, n, d, C, pivRM, pnorm, cell, blockhist, stream)
+          : rb == 128 ? launch_assign_mfma<64, 1, 4>(X, n, d, C, pivRM, pnorm, cell, blockhist, stream)
+                      : launch_assign_mfma<128, 1, 2>(X, n, d, C, pivRM, pnorm, cell, blockhist, stream);
+    } else {
+        e = rb == 256 ? launch_assign<256>(X, n, d, C, Cpad, pivT, pnorm, cell, blockhist, qpd, crad, stream)
+          : rb == 128 ? launch_assign<128>(X, n, d, C, Cpad, pivT, pnorm, cell, blockhist, qpd, crad, stream)
+                      : launch_assign<64>(X, n, d, C, Cpad, pivT, pnorm, cell, blockhist, qpd, crad, stream);
+    }
     if (e != hipSuccess) return e;
     // (the totals pass through the tail of the start array's own allocation: C + 1 .. 2 C + 1)
     int* col_total = cell_start + C + 1;
@@ -976,26 +1154,31 @@ hipError_t launch_locality(const float* Q, long long n, const float* R, long lon
         hipLaunchKernelGGL(fps_pivots_kernel, dim3(1), dim3(FPS_NT), 0, stream, R, m, d, g.cells, w.piv_rows);
         piv_rows = w.piv_rows;
     }
-    // the pivots as chosen (scratch copy), their mutual distances, the chain, the pivots in chain order
+    // the pivots as chosen (scratch copy), the leads' mutual distances, the chain, the pivots in chain order
     const unsigned pgrid = (unsigned)((g.cells_pad + 63) / 64);
     hipLaunchKernelGGL(pivots_kernel, dim3(pgrid), dim3(64), 0, stream, R, m, d, g.cells, g.cells_pad, w.pivT_tmp, w.pnorm_tmp,
                        piv_rows);
-    hipLaunchKernelGGL(pivot_dist_kernel, dim3((unsigned)g.cells), dim3(256), 0, stream, w.pivT_tmp, d, g.cells, g.cells_pad,
-                       w.pivD);
     {
-        const bool in_lds = g.cells <= CHAIN_LDS_CELLS;
-        const size_t lds = in_lds ? ((sizeof(_Float16) * (size_t)g.cells * g.cells_pad + 15) & ~(size_t)15) : 0;
+        const int stride = (g.cells + CHAIN_MAX - 1) / CHAIN_MAX;
+        const int S = (g.cells + stride - 1) / stride;
+        int* near = w.piv_rows + g.cells_pad;         // [cells]
+        int* chain = near + g.cells_pad;              // [S]
+        int* order = chain + g.cells_pad;             // [cells]
+        hipLaunchKernelGGL(pivot_dist_kernel, dim3((unsigned)g.cells), dim3(256), 0, stream, w.pivT_tmp, d, g.cells, g.cells_pad,
+                           stride, S, w.pivD, near);
+        const size_t lds = (sizeof(_Float16) * (size_t)S * S + 15) & ~(size_t)15;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_order_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(chain_order_kernel, dim3(1), dim3(64), lds, stream, w.pivD, g.cells, g.cells_pad, w.piv_rows + g.cells_pad,
-                           in_lds ? 1 : 0);
+        hipLaunchKernelGGL(chain_order_kernel, dim3(1), dim3(64), lds, stream, w.pivD, S, chain);
+        hipLaunchKernelGGL(chain_expand_kernel, dim3(1), dim3(1024), 0, stream, chain, near, g.cells, S, order);
+        hipLaunchKernelGGL(permute_pivots_kernel, dim3(pgrid), dim3(64), 0, stream, w.pivT_tmp, w.pnorm_tmp, d, g.cells,
+                           g.cells_pad, order, w.pivT, w.pnorm, w.pivRM);
     }
-    hipLaunchKernelGGL(permute_pivots_kernel, dim3(pgrid), dim3(64), 0, stream, w.pivT_tmp, w.pnorm_tmp, d, g.cells, g.cells_pad,
-                       w.piv_rows + g.cells_pad, w.pivT, w.pnorm);
-    hipError_t e = launch_cells(R, m, d, g, w.pivT, w.pnorm, w.cell_r, w.hist_r, w.cstart_r, w.perm_r, nullptr, w.crad, stream);
+    // (a pruned search needs exact bounds on both sides: both use the VALU kernel)
+    hipError_t e = launch_cells(R, m, d, g, w.pivT, w.pivRM, w.pnorm, w.cell_r, w.hist_r, w.cstart_r, w.perm_r, nullptr, w.crad, stream);
     if (e != hipSuccess) return e;
-    e = launch_cells(Q, n, d, g, w.pivT, w.pnorm, w.cell_q, w.hist_q, w.cstart_q, w.perm_q, w.qpd, nullptr, stream);
+    e = launch_cells(Q, n, d, g, w.pivT, w.pivRM, w.pnorm, w.cell_q, w.hist_q, w.cstart_q, w.perm_q, w.qpd, nullptr, stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(home_stages_kernel, dim3((unsigned)((g.nqb + 63) / 64)), dim3(64), 0, stream, w.cell_q, w.perm_q,
                        n, g.qpb, g.nqb, w.cstart_r, g.RT, g.m_pad, g.home_max, g.prune ? 0 : 1, w.home);
@@ -1027,8 +1210,8 @@ hipError_t launch_fused(const KnnGeometry& g, const FusedTuning& tn, const float
     // Three instantiations of every variant: the product kernel (dense), the pruned product kernel
     // (library variants up to 64 features) and a diagnostic one that carries per-wave counters,
     // the ablations (tuning bits: 1 no selection, 2 no staging, 4 no barrier, 8 empty candidate
-    // path, 16 candidate arithmetic only, 32 no seed pass) and the pruning code as well.
-    const int ablate = tn.ablate & 63;
+    // path, 16 candidate arithmetic only, 32 no seed pass, 128 no per-subtile test) and the pruning code as well.
+    const int ablate = tn.ablate & (63 | 128);
     const int kind = (diag != nullptr || ablate != 0) ? 1 : (prune.qpd != nullptr ? 2 : 0);
     const FusedLaunch a{Qp, Rp, rnorm, lists, pend_g, n, kt, ablate, kind, home, tau0, tau_out, prune, diag, stream};
     for (auto launch : {launch_fused_tu0, launch_fused_tu1, launch_fused_tu2, launch_fused_tu3, launch_fused_tu4}) {

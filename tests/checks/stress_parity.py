@@ -4,7 +4,7 @@ row counts, duplicates, unit rows).  Exits non-zero on the first difference.
 
     python tests/checks/stress_parity.py [--cases 60] [--seed 0] [--max-n 3000] [--max-m 40000]
     python tests/checks/stress_parity.py --locality [--cases 60]     shapes large enough for the locality partition
-                                  (n >= 2048, m >= 16384, d <= 64), random grid plans (pretend small GPUs, forced
+                                  (n >= 2048, m >= 16384), random grid plans (pretend small GPUs, forced
                                   chunk counts), random partition knobs, and searches merged over reference blocks
 """
 import argparse
@@ -42,12 +42,12 @@ def main():
         m = int(rng.integers(1, a.max_m))
         knobs, blocks = {}, 1
         if a.locality:
-            d = int(rng.choice([2, 7, 16, 30, 31, 33, 40, 50, 51, 64]))
+            d = int(rng.choice([2, 7, 16, 30, 31, 33, 40, 50, 51, 64, 64, 65, 100, 128, 200, 256]))
             n, m = int(rng.integers(2048, a.max_n)), int(rng.integers(16384, a.max_m))
             if rng.random() < 0.5:
                 knobs.update(slots=int(rng.choice([4, 8, 24])), tail_min_rows=int(rng.choice([512, 1024, 4096])))
             if rng.random() < 0.5:
-                knobs.update(cell_rows=int(rng.choice([200, 1024, 5000])), home_rows=int(rng.choice([640, 8192, 30000])),
+                knobs.update(cell_rows=int(rng.choice([40, 200, 1024, 5000])), home_rows=int(rng.choice([640, 8192, 30000])),
                              seed_rows=int(rng.choice([320, 3072, 12000])))
             blocks = int(rng.choice([1, 1, 2, 3]))
         k = int(min(m, rng.integers(1, 65)))

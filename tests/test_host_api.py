@@ -44,7 +44,9 @@ def test_size_queries_and_argument_checks_without_gpu():
     dense, pruned = ctypes.c_size_t(0), ctypes.c_size_t(0)
     assert lib.scmiac_knn_workspace_size(50000, 200000, 50, 30, 0, 0, ctypes.byref(dense)) == 0
     assert lib.scmiac_knn_workspace_size(50000, 200000, 50, 30, 0, 1, ctypes.byref(pruned)) == 0
-    assert pruned.value > dense.value + 50000 * 195 * 4     # the query-to-pivot bounds of 195 cells
+    assert pruned.value > 50000 * 195 * 4 and pruned.value != dense.value   # (the query-to-pivot bounds of 195 cells)
+    plan = _hip.knn_grid_plan(50000, 200000, 50, 30, mode="pruned")
+    assert plan["S"] == 1 and plan["St"] == 1 and plan["grid_blocks"] == plan["query_blocks"]   # one block per query block
     assert _hip.knn_grid_plan(50000, 200000, 50, 30, mode="pruned")["prunes"] == 1
     assert _hip.knn_grid_plan(50000, 200000, 50, 30, mode="dense")["prunes"] == 0
     assert _hip.knn_grid_plan(50000, 200000, 100, 30, mode="pruned")["prunes"] == 0   # beyond 64 features: dense

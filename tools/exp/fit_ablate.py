@@ -13,7 +13,9 @@ import bench  # noqa: E402
 
 U, V, _, _, d = bench.make_latents("c3", 98304, 400_000)
 q = torch.from_numpy(U).cuda()
-for label, kw in (("product kernel", {}), ("diag kernel, nothing ablated", dict(diag=True)), ("no selection", dict(ablate=1)),
+for label, kw in (("product kernel", {}), ("diag kernel, nothing ablated", dict(diag=True)), ("no selection", dict(ablate=1)), ("no selection, no per-subtile test", dict(ablate=129)),
+                  ("no selection, no test, no seed pass", dict(ablate=129 + 32)), ("no selection, no test, no barrier", dict(ablate=129 + 4)),
+                  ("no selection, no test, no staging", dict(ablate=129 + 2)),
                   ("empty candidate path", dict(ablate=8)), ("candidate arithmetic, no stores", dict(ablate=16)),
                   ("caller order, product", dict(no_locality=True))):
     _hip.set_tuning(**kw)
