@@ -136,7 +136,7 @@ def test_matrix_free_cca_host_logic(golden, tag, monkeypatch):
     import torch
     from scmiac_amd import cca_device
 
-    def row_perm_on_the_host(pivots, n):
+    def row_perm_on_the_host(pivots, n, status=None):
         # stand-in for the device kernel: LAPACK's row interchanges applied in order
         perm = np.arange(n, dtype=np.int64)
         for i, p in enumerate(pivots.numpy() - 1):
