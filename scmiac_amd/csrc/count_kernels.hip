@@ -314,7 +314,7 @@ hipError_t launch_closer_count(const KnnGeometry& g, const float* Q, const float
     SCMIAC_COUNT_CASE(8, 12, 320) SCMIAC_COUNT_CASE(15, 12, 320) SCMIAC_COUNT_CASE(16, 12, 320)
     SCMIAC_COUNT_CASE(20, 12, 320) SCMIAC_COUNT_CASE(25, 12, 320) SCMIAC_COUNT_CASE(32, 12, 256)
     SCMIAC_COUNT_CASE(40, 12, 128) SCMIAC_COUNT_CASE(50, 12, 128) SCMIAC_COUNT_CASE(64, 8, 128)
-    SCMIAC_COUNT_CASE(80, 8, 64) SCMIAC_COUNT_CASE(96, 8, 64) SCMIAC_COUNT_CASE(112, 8, 64)
+    SCMIAC_COUNT_CASE(80, 8, 64) SCMIAC_COUNT_CASE(96, 8, 64) SCMIAC_COUNT_CASE(100, 8, 64) SCMIAC_COUNT_CASE(112, 8, 64)
     SCMIAC_COUNT_CASE(128, 8, 64)
 #undef SCMIAC_COUNT_CASE
     return hipErrorInvalidValue;

@@ -873,7 +873,7 @@ __global__ __launch_bounds__(EX_NT) void exact_rows_kernel(
 // --------------------------------------------------------------------------------
 // host-side launchers
 // --------------------------------------------------------------------------------
-static const int kD2Sizes[] = {8, 15, 16, 20, 25, 32, 40, 50, 64, 80, 96, 112, 128};
+static const int kD2Sizes[] = {8, 15, 16, 20, 25, 32, 40, 50, 64, 80, 96, 100, 112, 128};
 int knn_pick_d2(int d) {
     int need = (d + 1) / 2;
     for (int v : kD2Sizes)
