@@ -216,7 +216,7 @@ def stored_traffic(workload, n_local, m_local, kernel_name):
 
 def kernel_source_hash():
     h = hashlib.sha256()
-    for name in ("knn_kernels.hip", "fused_knn.h", "fused_variants.h", "fused_common.h", "kernels.h"):
+    for name in ("knn_kernels.hip", "fused_knn.h", "fused_knn_share.h", "fused_variants.h", "fused_common.h", "kernels.h"):
         h.update((ROOT / "scmiac_amd" / "csrc" / name).read_bytes())
     return h.hexdigest()
 

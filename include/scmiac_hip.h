@@ -247,6 +247,26 @@ SCMIAC_API int scmiac_knn_diag_region(int64_t n, int64_t m, int d, int k, int sp
 SCMIAC_API int scmiac_knn_prune_stats_offset(int64_t n, int64_t m, int d, int k, int splits, size_t *offset);
 
 /*
+ * Stream sharing (no counterpart in the reference).  When the main region of a dense search's grid
+ * is a single round -- every block owns one (query block, reference chunk) stream from the first
+ * stage to the last, and the launch would end with the slowest of them -- the stages of a stream
+ * are handed out in runs through a counter, to its owner and to blocks that have run out of work
+ * of their own; those fill shortlists of their own, which the refine pass merges like a chunk's.
+ * The result does not depend on who scored which stage.
+ *   scmiac_knn_set_sharing(lists, run, min_left): lists 0 = the library's choice (two helper lists
+ *     per stream where the plan is a single round), -1 = never, 1..8 = this many wherever the plan
+ *     has a main region (test aid); run = stages handed out at a time (0: 4; at least 2);
+ *     min_left = stages a stream must have left to be joined (0: 8).  Part of the tuning state
+ *     (read once per call; scmiac_knn_set_tuning leaves these three as they are).
+ *   scmiac_knn_share_info: info[4] (host) = {helper lists per stream (0: a search of this shape
+ *     does not share), stages per run, min_left, streams}; *stats_offset = where such a search
+ *     leaves two uint64 counters in its workspace: {streams joined, stages scored by helpers}.
+ */
+SCMIAC_API int scmiac_knn_set_sharing(int lists, int run, int min_left);
+SCMIAC_API int scmiac_knn_share_info(int64_t n, int64_t m, int d, int k, int splits, int64_t *info,
+                                     size_t *stats_offset);
+
+/*
  * How scmiac_knn_search would lay its fused kernel's grid out for this problem (no
  * counterpart in the reference; no GPU work).  plan[10] (host memory):
  *   {query blocks, queries per block, S, rows per chunk, main query blocks,

@@ -42,6 +42,8 @@ _SIGNATURES = {
     "scmiac_knn_diag_region": ([_i64, _i64, _i32, _i32, _i32, _i32, _c.POINTER(_sz), _c.POINTER(_sz),
                                 _c.POINTER(_c.c_int)], _c.c_int),
     "scmiac_knn_prune_stats_offset": ([_i64, _i64, _i32, _i32, _i32, _c.POINTER(_sz)], _c.c_int),
+    "scmiac_knn_set_sharing": ([_i32] * 3, _c.c_int),
+    "scmiac_knn_share_info": ([_i64, _i64, _i32, _i32, _i32, _c.POINTER(_i64), _c.POINTER(_sz)], _c.c_int),
     "scmiac_knn_grid_plan": ([_i64, _i64, _i32, _i32, _i32, _i32, _c.POINTER(_i64)], _c.c_int),
     "scmiac_knn_kernel_name": ([_i64, _i64, _i32, _i32, _i32, _i32, _c.c_char_p, _sz], _c.c_int),
     "scmiac_lu_row_perm": ([_vp, _i32, _i64, _vp, _vp, _vp], _c.c_int),
@@ -305,6 +307,28 @@ def knn_prune_stats(n, m, d, k, splits=0, device=None):
     device = device or torch.device("cuda", torch.cuda.current_device())
     kept, dense = _ws_cache[device][off.value:off.value + 16].view(torch.int64).cpu().tolist()
     return kept, dense
+
+
+def set_sharing(*, lists=0, run=0, min_left=0):
+    """Stream-sharing knobs of the dense search (``set_sharing()`` resets them): ``lists`` helper
+    shortlists per stream (0 the library's choice, -1 never), ``run`` stages handed out at a time,
+    ``min_left`` stages a stream must have left to be joined."""
+    _check(load_library().scmiac_knn_set_sharing(int(lists), int(run), int(min_left)))
+
+
+def knn_share_info(n, m, d, k, splits=0, device=None, read_stats=False):
+    """How a dense search of this shape shares its streams: dict with ``lists`` (0: it does not),
+    ``run``, ``min_left``, ``streams`` and, with ``read_stats``, ``joined`` / ``helper_stages`` of the
+    last such search on ``device`` (read from the workspace it used)."""
+    info = (_i64 * 4)()
+    off = ctypes.c_size_t(0)
+    _check(load_library().scmiac_knn_share_info(n, m, d, k, splits, info, ctypes.byref(off)))
+    out = dict(zip(("lists", "run", "min_left", "streams"), (int(v) for v in info)))
+    if read_stats and out["lists"] > 0:
+        device = device or torch.device("cuda", torch.cuda.current_device())
+        joined, stages = _ws_cache[device][off.value:off.value + 16].view(torch.int64).cpu().tolist()
+        out["joined"], out["helper_stages"] = joined, stages
+    return out
 
 
 def knn_grid_plan(n, m, d, k, splits=0, mode=None):

@@ -45,6 +45,9 @@ struct KnnWs {
     unsigned long long* diag;  // per-wave counters of the fused kernel (diagnostic runs)
     size_t diag_offset, diag_bytes;
     size_t stats_offset;       // pruned search: {stages streamed, stages of the dense stream} (0: none)
+    ShareArgs share;           // stream sharing: queues, published thresholds, counters (cursor NULL: none)
+    size_t share_ctl_offset, share_ctl_bytes;  // what a search clears first: cursor, pub, claims, counters
+    size_t share_stats_offset;
     size_t total;
 };
 static KnnWs knn_carve(void* ws, long long n, long long m, int d, const KnnGeometry& g) {
@@ -102,6 +105,24 @@ static KnnWs knn_carve(void* ws, long long n, long long m, int d, const KnnGeome
             w.stats_offset = off;
             w.loc.stats = reinterpret_cast<unsigned long long*>(take(2 * sizeof(unsigned long long)));
         }
+    }
+    w.share = ShareArgs{};
+    w.share_ctl_offset = w.share_ctl_bytes = w.share_stats_offset = 0;
+    if (g.share > 0) {
+        const size_t streams = (size_t)g.blocks;
+        w.share_ctl_offset = off;
+        w.share.started = reinterpret_cast<unsigned*>(take(sizeof(unsigned)));
+        w.share.cursor = reinterpret_cast<unsigned*>(take(sizeof(unsigned) * streams));
+        w.share.pub = reinterpret_cast<unsigned*>(take(sizeof(unsigned) * streams));
+        w.share.claims = reinterpret_cast<unsigned*>(take(sizeof(unsigned) * streams));
+        w.share_stats_offset = off;
+        w.share.stats = reinterpret_cast<unsigned long long*>(take(2 * sizeof(unsigned long long)));
+        w.share_ctl_bytes = off - w.share_ctl_offset;
+        w.share.tau_pub = reinterpret_cast<float*>(take(sizeof(float) * streams * (size_t)g.qpb));
+        w.share.row0 = g.share_row0;
+        w.share.lists_per = g.share;
+        w.share.chunk = g.share_chunk;
+        w.share.min_left = g.share_min_left;
     }
     w.diag = reinterpret_cast<unsigned long long*>(p + off);
     w.diag_offset = off;
@@ -177,6 +198,17 @@ int scmiac_knn_prune_stats_offset(int64_t n, int64_t m, int d, int k, int splits
     return SCMIAC_OK;
 }
 
+int scmiac_knn_share_info(int64_t n, int64_t m, int d, int k, int splits, int64_t* info, size_t* stats_offset) {
+    if (!info || !stats_offset) return fail(SCMIAC_ERR_ARG, "NULL output pointer");
+    int rc = check_knn_args(n, m, d, k);
+    if (rc) return rc;
+    KnnGeometry g = knn_geometry(n, m, d, k, splits, SCMIAC_KNN_DENSE, knn_get_tuning());
+    if (g.D2 < 0) return fail(SCMIAC_ERR_ARG, "unsupported feature dimension %d", d);
+    info[0] = g.share; info[1] = g.share_chunk; info[2] = g.share_min_left; info[3] = g.share > 0 ? g.blocks : 0;
+    *stats_offset = g.share > 0 ? knn_carve(nullptr, n, m, d, g).share_stats_offset : 0;
+    return SCMIAC_OK;
+}
+
 int scmiac_knn_grid_plan(int64_t n, int64_t m, int d, int k, int splits, int mode, int64_t* plan) {
     if (!plan) return fail(SCMIAC_ERR_ARG, "plan is NULL");
     int rc = check_knn_args(n, m, d, k);
@@ -199,8 +231,11 @@ int scmiac_knn_kernel_name(int64_t n, int64_t m, int d, int k, int splits, int m
     KnnGeometry g = knn_geometry(n, m, d, k, splits, mode, tn);
     if (g.D2 < 0) return fail(SCMIAC_ERR_ARG, "unsupported feature dimension %d", d);
     const int kind = (tn.diag || (tn.ablate & (63 | 128))) ? 1 : (g.prune ? 2 : 0);
-    snprintf(buf, buf_bytes, "fused_knn_kernel<%d, %d, %d, %d, %s, %d>", g.D2, g.nw, g.RT, g.pcap,
-             g.gp ? "true" : "false", kind);
+    if (kind == 0 && g.share > 0)
+        snprintf(buf, buf_bytes, "fused_knn_share_kernel<%d, %d, %d, %d>", g.D2, g.nw, g.RT, g.pcap);
+    else
+        snprintf(buf, buf_bytes, "fused_knn_kernel<%d, %d, %d, %d, %s, %d>", g.D2, g.nw, g.RT, g.pcap,
+                 g.gp ? "true" : "false", kind);
     return SCMIAC_OK;
 }
 
@@ -232,6 +267,9 @@ int scmiac_knn_search(const float* q, int64_t n, const float* r, int64_t m, int 
         HIP_TRY(hipMemsetAsync(w.loc.crad, 0, sizeof(unsigned) * (size_t)g.cells_pad, stream), "memset radii");
         HIP_TRY(hipMemsetAsync(w.loc.stats, 0, 2 * sizeof(unsigned long long), stream), "memset counters");
     }
+    if (g.share > 0)
+        HIP_TRY(hipMemsetAsync(static_cast<unsigned char*>(workspace) + w.share_ctl_offset, 0, w.share_ctl_bytes, stream),
+                "memset stream queues");
     if (g.cells > 0) HIP_TRY(launch_locality(q, n, r, m, d, g, w.loc, stream), "locality partition");
     HIP_TRY(launch_pack(q, n, d, g, -2.0f, w.qp, g.rowf, nullptr, g.n_pad, w.maxnorm, w.loc.perm_q, stream), "pack queries");
     HIP_TRY(launch_pack(r, m, d, g, 1.0f, w.rp, g.ls, w.rnorm, g.m_pad, w.maxnorm, w.loc.perm_r, stream), "pack references");
@@ -255,12 +293,12 @@ int scmiac_knn_search(const float* q, int64_t n, const float* r, int64_t m, int 
     }
     if (slot >= 0) HIP_TRY(hipEventRecord(g_ev0[slot], stream), "event record");
     HIP_TRY(launch_fused(g, tn, w.qp, w.rp, w.rnorm, w.lists, w.pend, n, knn_threshold_rank(k, d), w.loc.home, tau0, w.tau_out,
-                         knn_prune_args(g, w.loc, w.maxnorm, n, m, d), tn.diag ? w.diag : nullptr, stream),
+                         knn_prune_args(g, w.loc, w.maxnorm, n, m, d), w.share, tn.diag ? w.diag : nullptr, stream),
             "fused distance + top-k");
     if (slot >= 0) HIP_TRY(hipEventRecord(g_ev1[slot], stream), "event record");
     HIP_TRY(launch_refine(q, w.qp, w.rp, d, n, g, w.lists, k, knn_threshold_rank(k, d), col_offset, merge, w.maxnorm, w.tau_out,
-                          w.loc.perm_q, w.loc.perm_r, idx, dist2, dist, lower_bound, uncertified_rows, n_uncertified,
-                          stream),
+                          w.loc.perm_q, w.loc.perm_r, w.share.claims, idx, dist2, dist, lower_bound, uncertified_rows,
+                          n_uncertified, stream),
             "refine");
     if (exact_fallback)  // the shortlists are dead once refine has run: their memory is the scratch
         HIP_TRY(launch_exact_rows(q, r, d, n, m, k, col_offset, uncertified_rows, n_uncertified, idx, dist2,
@@ -426,9 +464,22 @@ int scmiac_knn_set_tuning(int slots, int tail_min_rows, int no_tail, int ablate,
     t.no_locality = no_locality; t.home_rows = home_rows; t.seed_rows = seed_rows; t.cell_rows = cell_rows;
     t.has_variant = (nw > 0 || rt > 0) ? 1 : 0;
     t.nw = nw; t.rt = rt; t.pcap = pcap; t.gp = gp;
+    {   // (the sharing knobs have a call of their own and stay as they are)
+        const FusedTuning cur = knn_get_tuning();
+        t.share = cur.share; t.share_chunk = cur.share_chunk; t.share_min_left = cur.share_min_left;
+    }
     if (!knn_set_tuning(t))
         return fail(SCMIAC_ERR_ARG, "tuning rejected: negative value, or kernel variant %dx%dx%dx%d is not compiled",
                     nw, rt, pcap, gp);
+    return SCMIAC_OK;
+}
+
+int scmiac_knn_set_sharing(int lists, int chunk, int min_left) {
+    FusedTuning t = knn_get_tuning();
+    t.share = lists; t.share_chunk = chunk; t.share_min_left = min_left;
+    if (!knn_set_tuning(t))
+        return fail(SCMIAC_ERR_ARG, "sharing knobs rejected: lists %d outside -1..8, run of %d stages (0 or at least 2), "
+                    "min_left %d negative", lists, chunk, min_left);
     return SCMIAC_OK;
 }
 
@@ -492,6 +543,9 @@ int scmiac_closer_count(const float* q, int64_t n, const float* r, int64_t m, in
     HIP_TRY(hipMemsetAsync(status, 0, sizeof(int32_t), stream), "memset status");
     // the locality partition serves the count as well: with both sets in cell order the references
     // closer than a query's match sit in few stages, and every other subtile skips the counting
+    if (g.share > 0)
+        HIP_TRY(hipMemsetAsync(static_cast<unsigned char*>(workspace) + w.share_ctl_offset, 0, w.share_ctl_bytes, stream),
+                "memset stream queues");
     if (g.cells > 0) HIP_TRY(launch_locality(q, n, r, m, d, g, w.loc, stream), "locality partition");
     HIP_TRY(launch_pack(q, n, d, g, -2.0f, w.qp, g.rowf, nullptr, g.n_pad, w.maxnorm, w.loc.perm_q, stream), "pack queries");
     HIP_TRY(launch_pack(r, m, d, g, 1.0f, w.rp, g.ls, w.rnorm, g.m_pad, w.maxnorm, w.loc.perm_r, stream), "pack references");

@@ -676,7 +676,7 @@ int fused_occupancy_t() {
 // kernel and the diagnostic instantiation
 #define SCMIAC_DEFINE_FUSED_TU(N_, VARIANTS_)                                                                          \
     hipError_t launch_fused_tu##N_(const KnnGeometry& g, const FusedLaunch& a) {                                       \
-        if (a.kind == 2) return hipErrorNotFound; /* pruned product kernels live in a unit of their own */             \
+        if (a.kind >= 2) return hipErrorNotFound; /* pruned and stream-sharing kernels live in units of their own */   \
         VARIANTS_(SCMIAC_TU_LAUNCH_CASE)                                                                               \
         return hipErrorNotFound;                                                                                       \
     }                                                                                                                  \

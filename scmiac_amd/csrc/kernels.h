@@ -47,6 +47,14 @@ struct KnnGeometry {
     int home_max;          // most home stages a query block streams ahead of its chunk
     int seed_stages;       // home stages the fused kernel's seed pass looks at
     int prune;             // 1: pruned search (SCMIAC_KNN_PRUNED): blocks skip the cells out of their queries' reach
+    // Stream sharing (dense search whose main region is a single round of the grid): blocks that
+    // have run out of work join the streams of blocks that have not.  share = helper shortlists per
+    // stream (0: off; a stream = a block of the plan's grid: main region, then tail); their rows
+    // follow the ordinary ones from share_row0 on.
+    int share;
+    int share_chunk;       // stages handed out at a time
+    int share_min_left;    // stages a stream must have left to be worth joining
+    long long share_row0;  // first helper shortlist: row share_row0 + (slot * blocks + stream) * qpb + query
 };
 
 typedef unsigned short cell_t;  // number of a pivot cell (at most KNN_MAX_CELLS of them)
@@ -91,6 +99,9 @@ struct FusedTuning {
     int cell_rows;      // > 0: reference rows per pivot cell aimed at (default 1024)
     int has_variant;    // 1: use (nw, rt, pcap, gp) where that combination is compiled
     int nw, rt, pcap, gp;
+    int share;          // stream sharing: 0 the library's choice, -1 never, > 0 this many helper lists per stream wherever the plan allows
+    int share_chunk;    // > 0: stages handed out at a time (at least 2; default 4)
+    int share_min_left; // > 0: stages a stream must have left to be joined (default 8)
 };
 // One snapshot per C-ABI call: everything that call plans, carves and launches derives from it, so
 // a concurrent scmiac_knn_set_tuning cannot pair a geometry planned under one setting with a
@@ -132,6 +143,20 @@ struct PruneArgs {
     unsigned long long* stats; // [2]: stages streamed, stages of the dense stream (atomic adds)
 };
 
+// Stream sharing: the queues of the streams and what their helpers need.
+struct ShareArgs {
+    unsigned* started;          // [1] blocks of the grid that have started
+    unsigned* cursor;           // [streams] next position of the stream's rest to hand out (stages); NULL: no sharing
+    unsigned* pub;              // [streams] 0: the owner has not published its thresholds yet; else stages of the rest + 1
+    unsigned* claims;           // [streams] helper lists claimed (may overshoot lists_per)
+    float* tau_pub;             // [streams][qpb] the owner's thresholds after its home stages
+    long long row0;             // first helper shortlist row
+    int lists_per;              // helper lists per stream
+    int chunk;                  // stages handed out at a time (>= 2)
+    int min_left;               // stages a stream must have left to be worth joining
+    unsigned long long* stats;  // [2]: streams joined, stages scored by helpers (atomic adds)
+};
+
 // arguments of one launch of the fused kernel that are not part of the geometry
 struct FusedLaunch {
     const float* Qp;
@@ -142,11 +167,12 @@ struct FusedLaunch {
     long long n;
     int kt;
     int ablate;                // ablation bits (diagnostic instantiation only)
-    int kind;                  // 0 product dense kernel, 1 diagnostic instantiation, 2 product pruned kernel
+    int kind;                  // 0 product dense kernel, 1 diagnostic instantiation, 2 product pruned kernel, 3 stream sharing
     const int* home;
     const float* tau0;
     float* tau_out;
     PruneArgs prune;
+    ShareArgs share;
     unsigned long long* diag;
     hipStream_t stream;
 };
@@ -163,6 +189,9 @@ int fused_occupancy_tu3(const KnnGeometry& g);
 // pruned product instantiations (the library's own variants up to 64 features): a unit of their own
 hipError_t launch_fused_tu4(const KnnGeometry& g, const FusedLaunch& a);
 bool fused_pruned_compiled_tu4(const KnnGeometry& g);
+// stream-sharing instantiations (the same variants): a unit of their own
+hipError_t launch_fused_tu5(const KnnGeometry& g, const FusedLaunch& a);
+bool fused_share_compiled_tu5(const KnnGeometry& g);
 
 hipError_t launch_pack(const float* X, long long n, int d, const KnnGeometry& g, float scale, float* Xp,
                        int ld, float* norms, long long n_pad, unsigned* maxnorm_bits, const int* perm,
@@ -176,12 +205,14 @@ PruneArgs knn_prune_args(const KnnGeometry& g, const LocalityWs& loc, const unsi
                          int d);
 hipError_t launch_fused(const KnnGeometry& g, const FusedTuning& tn, const float* Qp, const float* Rp, const float* rnorm,
                         unsigned long long* lists, void* pend_g, long long n, int kt, const int* home,
-                        const float* tau0, float* tau_out, const PruneArgs& prune, unsigned long long* diag, hipStream_t stream);
+                        const float* tau0, float* tau_out, const PruneArgs& prune, const ShareArgs& share,
+                        unsigned long long* diag, hipStream_t stream);
+// (share_claims: helper lists claimed per stream, NULL without stream sharing)
 hipError_t launch_refine(const float* Q, const float* Qp, const float* Rp, int d, long long n, const KnnGeometry& g,
                          const unsigned long long* lists, int k, int kt, long long col_offset, int merge,
                          const unsigned* maxnorm_bits, const float* tau_lists, const int* perm_q, const int* perm_r,
-                         int* idx, float* d2, float* dist, double* lb, int* fail_rows, int* n_fail,
-                         hipStream_t stream);
+                         const unsigned* share_claims, int* idx, float* d2, float* dist, double* lb, int* fail_rows,
+                         int* n_fail, hipStream_t stream);
 hipError_t launch_exact_rows(const float* Q, const float* R, int d, long long n, long long m, int k,
                              long long col_offset, const int* rows, const int* n_rows, int* idx,
                              float* d2, float* dist, void* scratch, size_t scratch_bytes,

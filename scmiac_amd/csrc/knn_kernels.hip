@@ -642,6 +642,8 @@ __global__ __launch_bounds__(256) void refine_kernel(
     const float* __restrict__ tau_lists,  // [shortlists]: the threshold each list ended with
     const int* __restrict__ perm_q,       // packed query position -> caller's row (NULL: the same)
     const int* __restrict__ perm_r,       // packed reference row -> caller's row (NULL: the same)
+    const unsigned* __restrict__ share_claims,  // [streams] helper lists claimed (NULL: no stream sharing)
+    int share_lists, long long share_row0,      // helper lists per stream; their first shortlist row
     int* __restrict__ out_idx,
     float* __restrict__ out_d2, float* __restrict__ out_dist, double* __restrict__ lower_bound,
     int* __restrict__ fail_rows, int* __restrict__ n_fail) {
@@ -668,9 +670,21 @@ __global__ __launch_bounds__(256) void refine_kernel(
     const long long tail_q0 = (long long)tail.qb0 * tail.qpb;
     const bool in_tail = qp >= tail_q0;
     const int S_q = in_tail ? tail.St : S;
-    for (int s = 0; s < S_q; ++s) {
+    // With stream sharing a stream (chunk s of a main-region query block: stream s qb0 + qb; piece s
+    // of a tail query block: stream block0 + (qb - qb0) St + s) may have helper lists as well: slot
+    // h for every h below the stream's claim count.
+    const int per_chunk = share_claims != nullptr ? 1 + share_lists : 1;
+    const long long n_streams = (long long)tail.block0 + (tail.rows / tail.qpb) * tail.St;
+    for (int it = 0; it < S_q * per_chunk; ++it) {
+        const int s = it / per_chunk, h = it - s * per_chunk - 1;  // h = -1: the chunk's own list
         long long lrow = (long long)s * n_pad + qp;
         if (in_tail && s > 0) lrow = tail.lists_row0 + (long long)(s - 1) * tail.rows + (qp - tail_q0);
+        if (h >= 0) {
+            const long long qb = qp / tail.qpb;
+            const long long vstream = in_tail ? tail.block0 + (qb - tail.qb0) * tail.St + s : (long long)s * tail.qb0 + qb;
+            if ((unsigned)h >= share_claims[vstream]) continue;  // (wave-uniform) nobody filled this one
+            lrow = share_row0 + ((long long)h * n_streams + vstream) * tail.qpb + (qp - qb * tail.qpb);
+        }
         u64 e = lists[lrow * 64 + lane];
         unsigned ridx = (unsigned)e;
         // every reference of this chunk outside the list scores at least this much; a threshold
@@ -902,6 +916,8 @@ bool knn_set_tuning(const FusedTuning& t) {
     }
     if (t.slots < 0 || t.tail_min_rows < 0 || t.ablate < 0 || t.home_rows < 0 || t.seed_rows < 0 || t.cell_rows < 0)
         return false;
+    // (runs of fewer than two stages would ask for the next run before the answer to the last request is in)
+    if (t.share < -1 || t.share > 8 || t.share_chunk < 0 || t.share_chunk == 1 || t.share_min_left < 0) return false;
     std::lock_guard<std::mutex> lock(g_plan_mu);
     g_tuning = t;
     return true;
@@ -953,6 +969,7 @@ static int fused_concurrent_blocks(const KnnGeometry& g) {
 }
 
 bool fused_pruned_compiled(const KnnGeometry& g) { return fused_pruned_compiled_tu4(g); }
+static bool fused_share_compiled(const KnnGeometry& g) { return fused_share_compiled_tu5(g); }
 
 KnnGeometry knn_geometry(long long n, long long m, int d, int k, int splits, int mode, const FusedTuning& tn) {
     KnnGeometry g{};
@@ -1002,8 +1019,13 @@ KnnGeometry knn_geometry(long long n, long long m, int d, int k, int splits, int
     // A pruned search streams a query block's own cluster and little else: cutting its reference
     // range into chunks would buy no balance and cost every chunk but one the sight of its
     // queries' own cells (the thresholds the reach test lives on).  One block per query block.
+    // (One case apart: between one and two rounds of query blocks -- 261 of them are two rounds on
+    // 256 compute units, which doubles the time of a search whose data turn out not to prune.
+    // There the dense plan is kept, whose main region is one round of whole streams and whose tail
+    // pieces fill the rest.  Cutting further, as the dense plan does for fewer or more query blocks,
+    // triples the time of a search that does prune: measured at 250 000 x 1 000 000.)
     const bool want_prune = mode == 1 && g.cells > 0 && fused_pruned_compiled(g);
-    if (want_prune && splits <= 0) {
+    if (want_prune && splits <= 0 && !(g.nqb > slots && g.nqb <= 2 * slots)) {
         // (S = St = 1)
     } else if (splits > 0) {
         S = splits;
@@ -1076,6 +1098,22 @@ KnnGeometry knn_geometry(long long n, long long m, int d, int k, int splits, int
     // block's stage list fits 16-bit stage numbers; the dense search otherwise
     const long long longest = g.chunk_rows > t.chunk_rows ? g.chunk_rows : t.chunk_rows;
     g.prune = (want_prune && longest / g.RT < 65535) ? 1 : 0;
+    // Stream sharing: when the main region is a single round of the grid (every block owns its
+    // stream from the first stage to the last, and the launch would end with the slowest of them)
+    // and the streams are long enough to be worth handing out in runs.  Two helper lists per
+    // stream.  (Not for the diagnostic instantiation, which has no such kernel.)
+    g.share = 0; g.share_chunk = 0; g.share_min_left = 0; g.share_row0 = g.list_rows;
+    if (mode == 0 && !g.prune && tn.share >= 0 && !tn.diag && !(tn.ablate & (63 | 128)) && g.blocks >= 2 &&
+        g.blocks <= 4096 && fused_share_compiled(g)) {
+        const int chunk = tn.share_chunk > 0 ? tn.share_chunk : 4;
+        const bool one_round = t.block0 <= slots && g.blocks <= 2 * slots && longest / g.RT >= 12 * chunk;
+        if (tn.share > 0 || one_round) {
+            g.share = tn.share > 0 ? tn.share : 2;
+            g.share_chunk = chunk;
+            g.share_min_left = tn.share_min_left > 0 ? tn.share_min_left : 8;
+            g.list_rows += (long long)g.share * g.blocks * g.qpb;
+        }
+    }
     return g;
 }
 
@@ -1204,17 +1242,19 @@ hipError_t launch_seed_tau(const float* Q, const int* perm_q, int d, long long n
 
 hipError_t launch_fused(const KnnGeometry& g, const FusedTuning& tn, const float* Qp, const float* Rp, const float* rnorm,
                         unsigned long long* lists, void* pend_g_, long long n, int kt, const int* home,
-                        const float* tau0, float* tau_out, const PruneArgs& prune, unsigned long long* diag,
-                        hipStream_t stream) {
+                        const float* tau0, float* tau_out, const PruneArgs& prune, const ShareArgs& share,
+                        unsigned long long* diag, hipStream_t stream) {
     uint2* pend_g = static_cast<uint2*>(pend_g_);
     // Three instantiations of every variant: the product kernel (dense), the pruned product kernel
     // (library variants up to 64 features) and a diagnostic one that carries per-wave counters,
     // the ablations (tuning bits: 1 no selection, 2 no staging, 4 no barrier, 8 empty candidate
     // path, 16 candidate arithmetic only, 32 no seed pass, 128 no per-subtile test) and the pruning code as well.
     const int ablate = tn.ablate & (63 | 128);
-    const int kind = (diag != nullptr || ablate != 0) ? 1 : (prune.qpd != nullptr ? 2 : 0);
-    const FusedLaunch a{Qp, Rp, rnorm, lists, pend_g, n, kt, ablate, kind, home, tau0, tau_out, prune, diag, stream};
-    for (auto launch : {launch_fused_tu0, launch_fused_tu1, launch_fused_tu2, launch_fused_tu3, launch_fused_tu4}) {
+    // A fourth one where the plan shares streams (kind 3, fused_knn_share.h).
+    const int kind = (diag != nullptr || ablate != 0) ? 1 : (prune.qpd != nullptr ? 2 : (g.share > 0 && share.cursor != nullptr ? 3 : 0));
+    const FusedLaunch a{Qp, Rp, rnorm, lists, pend_g, n, kt, ablate, kind, home, tau0, tau_out, prune, share, diag, stream};
+    for (auto launch : {launch_fused_tu0, launch_fused_tu1, launch_fused_tu2, launch_fused_tu3, launch_fused_tu4,
+                        launch_fused_tu5}) {
         const hipError_t e = launch(g, a);
         if (e != hipErrorNotFound) return e;  // hipErrorNotFound: the variant (of this kind) is not that file's
     }
@@ -1235,8 +1275,8 @@ PruneArgs knn_prune_args(const KnnGeometry& g, const LocalityWs& loc, const unsi
 hipError_t launch_refine(const float* Q, const float* Qp, const float* Rp, int d, long long n, const KnnGeometry& g,
                          const unsigned long long* lists, int k, int kt, long long col_offset, int merge,
                          const unsigned* maxnorm_bits, const float* tau_lists, const int* perm_q, const int* perm_r,
-                         int* idx, float* d2, float* dist, double* lb, int* fail_rows, int* n_fail,
-                         hipStream_t stream) {
+                         const unsigned* share_claims, int* idx, float* d2, float* dist, double* lb, int* fail_rows,
+                         int* n_fail, hipStream_t stream) {
     // rounding-error model of the fused score s against T = |q|^2 + |r|^2 - 2 q.r (exact),
     // with gamma_n = n u / (1 - n u), u = 2^-24: the MFMA chain (2*D2 products) and the norm
     // chain (d terms) are each a float32 inner product, so
@@ -1248,8 +1288,8 @@ hipError_t launch_refine(const float* Q, const float* Qp, const float* Rp, int d
     knn_error_model(d, g, &err_abs_coef, &rel_keep);
     dim3 block(256), grid((unsigned)((n + 3) / 4));
     hipLaunchKernelGGL(refine_kernel, grid, block, 0, stream, Q, Qp, Rp, g.rowf, g.ls, d, n, g.n_pad, lists, g.S, g.tail, k, kt,
-                       col_offset, merge, err_abs_coef, rel_keep, maxnorm_bits, tau_lists, perm_q, perm_r, idx, d2, dist,
-                       lb, fail_rows, n_fail);
+                       col_offset, merge, err_abs_coef, rel_keep, maxnorm_bits, tau_lists, perm_q, perm_r,
+                       g.share > 0 ? share_claims : nullptr, g.share, g.share_row0, idx, d2, dist, lb, fail_rows, n_fail);
     return hipGetLastError();
 }
 

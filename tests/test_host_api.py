@@ -52,7 +52,18 @@ def test_size_queries_and_argument_checks_without_gpu():
     assert _hip.knn_grid_plan(50000, 200000, 100, 30, mode="pruned")["prunes"] == 0   # beyond 64 features: dense
     assert _hip.knn_grid_plan(50000, 200000, 100, 30)["cells"] == 195                # ... but partitioned
     assert _hip.knn_kernel_name(50000, 200000, 50, 30, mode="pruned") == "fused_knn_kernel<25, 12, 320, 64, true, 2>"
-    assert _hip.knn_kernel_name(50000, 200000, 50, 30) == "fused_knn_kernel<25, 12, 320, 64, true, 0>"
+    # 131 query blocks on 256 compute units: a single round, whose streams are shared ...
+    assert _hip.knn_kernel_name(50000, 200000, 50, 30) == "fused_knn_share_kernel<25, 12, 320, 64>"
+    assert _hip.knn_share_info(50000, 200000, 50, 30)["lists"] == 2
+    # ... several rounds: the plain dense kernel
+    assert _hip.knn_kernel_name(500000, 200000, 50, 30) == "fused_knn_kernel<25, 12, 320, 64, true, 0>"
+    assert _hip.knn_share_info(500000, 200000, 50, 30)["lists"] == 0
+    assert lib.scmiac_knn_set_sharing(0, 1, 0) == 1 and b"run of 1" in lib.scmiac_last_error()
+    _hip.set_sharing(lists=-1)
+    try:
+        assert _hip.knn_kernel_name(50000, 200000, 50, 30) == "fused_knn_kernel<25, 12, 320, 64, true, 0>"
+    finally:
+        _hip.set_sharing()
     off = ctypes.c_size_t(0)
     assert lib.scmiac_knn_prune_stats_offset(50000, 200000, 50, 30, 0, ctypes.byref(off)) == 0 and 0 < off.value < pruned.value
     assert lib.scmiac_knn_prune_stats_offset(500, 2000, 50, 30, 0, ctypes.byref(off)) == 1

@@ -3,7 +3,7 @@ sys.path.insert(0, '/root/repo')
 import numpy as np, torch
 import bench
 from scmiac_amd import _hip
-for wl, n, m in (("c2", None, None), ("c3", None, None), ("cca30", None, None), ("c5shard", None, None)):
+for wl, n, m in (("c2", None, None), ("c4", None, None), ("c2", 30000, 500000), ("c3", 250000, None), ("c3", None, None), ("cca30", None, None), ("c5shard", None, None)):
     U, V, _, _, d = bench.make_latents(wl, n, m)
     q, r = torch.from_numpy(U).cuda(), torch.from_numpy(V).cuda()
     res = {}
