@@ -372,6 +372,11 @@ def main():
                     "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                     "traffic": traffic, "traffic_source": traffic_source,
                     "kernel_ms": round(fused_avg_ms, 3), "flops_per_launch": flops}
+        share = _hip.knn_share_info(n_local, r_hi - r_lo, d, k, device=dev, read_stats=True)
+        if share["lists"] > 0:  # single-round plan: blocks out of work joined unfinished streams (last step's counters)
+            roofline["stream_sharing"] = {"streams": share["streams"], "helper_lists_per_stream": share["lists"],
+                                          "stages_per_run": share["run"], "streams_joined": share["joined"],
+                                          "stages_scored_by_helpers": share["helper_stages"]}
 
     out = {
         "metric": "anchor-search query cells/sec (N=M=1M, d=50, k=30)" if args.workload == "c3" and not (args.n or args.m)

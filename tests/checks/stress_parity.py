@@ -3,7 +3,7 @@ the CPU oracle over random shapes (every feature-dimension bucket of the kernels
 row counts, duplicates, unit rows).  Exits non-zero on the first difference.
 
     python tests/checks/stress_parity.py [--cases 60] [--seed 0] [--max-n 3000] [--max-m 40000]
-    python tests/checks/stress_parity.py --locality [--cases 60]     shapes large enough for the locality partition
+    python tests/checks/stress_parity.py --locality [--prune | --share] [--cases 60]     shapes large enough for the locality partition
                                   (n >= 2048, m >= 16384), random grid plans (pretend small GPUs, forced
                                   chunk counts), random partition knobs, and searches merged over reference blocks
 """
@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--max-m", type=int, default=40000)
     ap.add_argument("--locality", action="store_true")
     ap.add_argument("--prune", action="store_true", help="with --locality: the pruned search (mode='pruned')")
+    ap.add_argument("--share", action="store_true",
+                    help="with --locality: stream sharing forced on with random (helper lists, stages per run, stages left)")
     a = ap.parse_args()
     if a.locality:
         a.max_n, a.max_m = max(a.max_n, 9000), max(a.max_m, 70000)
@@ -68,8 +70,16 @@ def main():
         idx_o, d2_o = oracle.knn_dist2(q, r, k)
         _hip.set_default_mode("pruned" if a.prune else "dense")
         _hip.set_tuning(**knobs)
+        share = {}
+        if a.share:
+            share = dict(lists=int(rng.integers(1, 5)), run=int(rng.choice([2, 3, 4, 8])), min_left=int(rng.choice([1, 2, 8])))
+            _hip.set_sharing(**share)
+        joined = None
         if blocks == 1:
-            st = _hip.knn_search(qd, rd, k, splits=int(rng.choice([0, 0, 3])) if a.locality else 0)
+            splits = int(rng.choice([0, 0, 3])) if a.locality else 0
+            st = _hip.knn_search(qd, rd, k, splits=splits)
+            if share:
+                joined = _hip.knn_share_info(n, m, d, k, splits=splits, read_stats=True).get("joined")
         else:  # reference blocks merged one after the other, direct evaluation for what stays uncertified
             cuts = np.linspace(0, m, blocks + 1).astype(int)
             st = None
@@ -86,6 +96,9 @@ def main():
         cnt = _hip.closer_count(qd, rd, match=torch.from_numpy(match).cuda()).cpu().numpy()
         ok2 = np.array_equal(cnt, cnt_o.astype(np.int64))
         _hip.set_tuning()
+        _hip.set_sharing()
+        if share:
+            knobs = dict(knobs, share=share, joined=joined)
         print(f"case {case:3d} n={n:5d} m={m:6d} d={d:3d} k={k:2d}  knn {'ok' if ok else 'DIFFERS'}  "
               f"count {'ok' if ok2 else 'DIFFERS'}  uncertified={int(st.n_uncertified.item())} blocks={blocks} {knobs}", flush=True)
         if not (ok and ok2):

@@ -15,6 +15,10 @@ sets = [("off", dict(lists=-1)), ("default", {}), ("2/4/8", dict(lists=2, run=4,
         ("3/8/12", dict(lists=3, run=8, min_left=12)), ("2/16/24", dict(lists=2, run=16, min_left=24)),
         ("1/8/12", dict(lists=1, run=8, min_left=12)), ("4/4/6", dict(lists=4, run=4, min_left=6))]
 shapes = [("c2", None, None), ("c4", None, None), ("c2", 40000, 60000), ("c2", 50000, None), ("c3", 60000, 500000)]
+if len(sys.argv) > 1 and sys.argv[1] == "shards":
+    shapes = [("c3", 125000, None), ("c3", 250000, None), ("c5shard", 125000, None)]
+    sets = [("off", dict(lists=-1)), ("2/4/8", dict(lists=2, run=4, min_left=8)), ("2/8/16", dict(lists=2, run=8, min_left=16)),
+            ("3/16/32", dict(lists=3, run=16, min_left=32))]
 for name, n, m in shapes:
     U, V, _, _, d = bench.make_latents(name, n, m)
     q, r = torch.from_numpy(U).cuda(), torch.from_numpy(V).cuda()
@@ -23,7 +27,7 @@ for name, n, m in shapes:
     for label, kw in sets:
         _hip.set_sharing(**kw)
         best = 1e9
-        for _ in range(5):
+        for _ in range(5 if q.shape[0] * r.shape[0] < 5e10 else 2):
             _hip.set_timing(True)
             st = _hip.knn_search(q, r, 30, exact_fallback=False)
             ms, _ = _hip.fused_ms()
