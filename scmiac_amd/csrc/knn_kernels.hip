@@ -1019,13 +1019,14 @@ KnnGeometry knn_geometry(long long n, long long m, int d, int k, int splits, int
     // A pruned search streams a query block's own cluster and little else: cutting its reference
     // range into chunks would buy no balance and cost every chunk but one the sight of its
     // queries' own cells (the thresholds the reach test lives on).  One block per query block.
-    // (One case apart: between one and two rounds of query blocks -- 261 of them are two rounds on
-    // 256 compute units, which doubles the time of a search whose data turn out not to prune.
-    // There the dense plan is kept, whose main region is one round of whole streams and whose tail
-    // pieces fill the rest.  Cutting further, as the dense plan does for fewer or more query blocks,
-    // triples the time of a search that does prune: measured at 250 000 x 1 000 000.)
+    // (One case apart: a few query blocks more than one round -- 261 of them are two rounds on 256
+    // compute units, which doubles the time of a search whose data turn out not to prune.  There
+    // the dense plan is kept, whose main region is one round of whole streams and whose tail pieces
+    // fill the rest.  Only there: every piece pays a seed pass over its queries' own cells and a
+    // reach test of its own, which doubled the time of a search that does prune at 326 query blocks
+    // and tripled it at 652.)
     const bool want_prune = mode == 1 && g.cells > 0 && fused_pruned_compiled(g);
-    if (want_prune && splits <= 0 && !(g.nqb > slots && g.nqb <= 2 * slots)) {
+    if (want_prune && splits <= 0 && !(g.nqb > slots && g.nqb - slots <= slots / 8)) {
         // (S = St = 1)
     } else if (splits > 0) {
         S = splits;

@@ -7,7 +7,9 @@
   the 2M reference rows arriving as 8 blocks of 250k, merged through ``col_offset`` /
   ``merge`` with the direct-evaluation pass per block afterwards, exactly what ``knn_ring``
   does on 8 ranks; per-block timings and uncertified-row counts are written to
-  ``gpurun_out/`` for the record.
+  ``gpurun_out/`` for the record;
+* on both, the pruned search (``mode="pruned"``): the identical table from a few per cent of the
+  reference stages.
 """
 import json
 import sys
@@ -64,8 +66,16 @@ def test_headline_workload_full_size():
     # the same table again: bit-identical (nothing depends on scheduling)
     st2 = _hip.knn_search(q, r, k)
     assert torch.equal(st.idx, st2.idx) and torch.equal(st.dist2, st2.dist2)
+    del st2
+    # the pruned search (SCMIAC_KNN_PRUNED): the same table from a few per cent of the stages
+    assert _hip.knn_grid_plan(n, m, d, k, mode="pruned")["prunes"] == 1
+    pr = _hip.knn_search(q, r, k, mode="pruned")
+    assert torch.equal(st.idx, pr.idx) and torch.equal(st.dist2, pr.dist2)
+    kept, dense = _hip.knn_prune_stats(n, m, d, k)
+    assert 0 < kept < 0.1 * dense, (kept, dense)
     _record("full_size_c3.json", {"n": n, "m": m, "d": d, "k": k, "rows_vs_oracle": len(rows), "index_mismatches": 0,
-                                  "uncertified_rows": int(st.n_uncertified.item())})
+                                  "uncertified_rows": int(st.n_uncertified.item()),
+                                  "pruned_search_identical": True, "pruned_kept_stage_fraction": round(kept / dense, 4)})
 
 
 def test_ring_workload_one_rank_share_in_eight_blocks():
@@ -98,6 +108,12 @@ def test_ring_workload_one_rank_share_in_eight_blocks():
     ms_whole, _ = _hip.fused_ms()
     _hip.set_timing(False)
     assert torch.equal(whole.idx, state.idx) and torch.equal(whole.dist2, state.dist2)
+    # ... and so does the pruned search of the whole stream
+    pr = _hip.knn_search(q, r, k, mode="pruned")
+    assert torch.equal(whole.idx, pr.idx) and torch.equal(whole.dist2, pr.dist2)
+    kept, dense = _hip.knn_prune_stats(n, m, d, k)
+    assert 0 < kept < 0.1 * dense, (kept, dense)
+    del pr
     # blocks 2..8 start from the running k-th distances: each runs within 3 points of peak of
     # the single 2M-row stream
     frac_whole = 2.0 * n * m * d / (ms_whole * 1e-3) / 157.3e12

@@ -20,7 +20,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--stats", required=True)
     ap.add_argument("--pmc", nargs="+", required=True)
-    ap.add_argument("--bench", required=True)
+    ap.add_argument("--bench", default=None, help="log of a bench.py run whose JSON line becomes <tag>_bench.json")
     ap.add_argument("--tag", default="r01_c3")
     ap.add_argument("--workload", default="c3")
     ap.add_argument("--n-local", type=int, default=None, help="query rows per launch (default: the workload's, or --n)")
@@ -74,8 +74,9 @@ def main():
                "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE doubled as the gfx950 "
                        "correction for wide coalesced reads prescribes; one launch = one table of this workload"},
               open(traffic_file, "w"), indent=1)
-    line = [l for l in open(a.bench).read().splitlines() if l.startswith("{")][-1]
-    (out_dir / f"{a.tag}_bench.json").write_text(line + "\n")
+    if a.bench:
+        line = [l for l in open(a.bench).read().splitlines() if l.startswith("{")][-1]
+        (out_dir / f"{a.tag}_bench.json").write_text(line + "\n")
     print(json.dumps(out["_derived"], indent=1))
 
 
