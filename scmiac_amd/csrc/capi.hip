@@ -500,6 +500,12 @@ int scmiac_knn_fused_ms(float* total_ms, int* launches) {
 
 // workspace of a count: the k-NN carve-up, with the thresholds and counts in the (unused)
 // shortlist region and the parked references in the pending-candidate region
+// (the count kernel shares no streams: no helper lists in its plan)
+static FusedTuning count_tuning() {
+    FusedTuning t = knn_get_tuning();
+    t.share = -1;
+    return t;
+}
 static size_t count_pend_offset_total(const KnnGeometry& g, int64_t n, int64_t m, int d, KnnWs* w_out) {
     KnnWs w = knn_carve(nullptr, n, m, d, g);
     if (w_out) *w_out = w;
@@ -510,7 +516,7 @@ int scmiac_closer_count_workspace_size(int64_t n, int64_t m, int d, size_t* byte
     if (!bytes) return fail(SCMIAC_ERR_ARG, "bytes is NULL");
     int rc = check_knn_args(n, m, d, 1);
     if (rc) return rc;
-    KnnGeometry g = knn_geometry(n, m, d, 30, 0, SCMIAC_KNN_DENSE, knn_get_tuning());
+    KnnGeometry g = knn_geometry(n, m, d, 30, 0, SCMIAC_KNN_DENSE, count_tuning());
     if (g.D2 < 0) return fail(SCMIAC_ERR_ARG, "unsupported feature dimension %d", d);
     *bytes = count_pend_offset_total(g, n, m, d, nullptr);
     return SCMIAC_OK;
@@ -525,7 +531,7 @@ int scmiac_closer_count(const float* q, int64_t n, const float* r, int64_t m, in
     if (m == 0) return fail(SCMIAC_ERR_ARG, "no reference rows");
     if (!q || !r || !counts || !status || !workspace) return fail(SCMIAC_ERR_ARG, "NULL device pointer");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    KnnGeometry g = knn_geometry(n, m, d, 30, 0, SCMIAC_KNN_DENSE, knn_get_tuning());
+    KnnGeometry g = knn_geometry(n, m, d, 30, 0, SCMIAC_KNN_DENSE, count_tuning());
     if (g.D2 < 0) return fail(SCMIAC_ERR_ARG, "unsupported feature dimension %d", d);
     KnnWs w0;
     size_t total = count_pend_offset_total(g, n, m, d, &w0);

@@ -13,7 +13,8 @@
     X(40, 12, 128, 64, 1) X(50, 12, 128, 64, 1) X(64, 8, 128, 64, 1) X(25, 12, 256, 32, 1) X(25, 12, 320, 32, 1)
 #define SCMIAC_FUSED_VARIANTS_3(X) \
     X(80, 8, 64, 64, 1) X(96, 8, 64, 64, 1) X(100, 8, 64, 64, 1) X(112, 8, 64, 64, 1) X(128, 8, 64, 64, 1)
-// the library's own variants up to 64 features also exist as pruned product kernels (unit 4)
+// the library's own variants up to 64 features also exist as pruned product kernels (unit 4) and as
+// stream-sharing kernels (unit 5, fused_knn_share.h)
 #define SCMIAC_FUSED_VARIANTS_PRUNED(X) \
     X(8, 12, 320, 64, 1) X(15, 12, 320, 64, 1) X(16, 12, 320, 64, 1) X(20, 12, 320, 64, 1) X(25, 12, 320, 64, 1) \
     X(32, 12, 256, 64, 1)

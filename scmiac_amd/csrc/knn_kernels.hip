@@ -3,8 +3,9 @@
 // float32 direct-difference search.
 //
 // Pipeline of one scmiac_knn_search call (all on one stream, no host sync):
-//   locality       (d <= 64, large sets) both sets regrouped by nearest pivot: permutations, and
-//                  per query block the stages of the reference image that hold its cell ("home")
+//   locality       (large sets) both sets regrouped by nearest pivot, the cells laid out along a
+//                  nearest-neighbour chain over the pivots: permutations, and per query block the
+//                  stages of the reference image round its queries' own cells ("home")
 //   pack_rows      Q, R  -> MFMA-friendly padded copies (in cell order), |r|^2, max |r|^2
 //   seed_tau       (merge mode) thresholds to start from, out of the running k-th distances
 //   fused_knn      seed pass over the home rows (group minima -> a starting threshold per query),
@@ -18,7 +19,10 @@
 //                  shortlist can belong to the top-k
 //   exact_rows     rows whose certificate failed are searched by direct evaluation
 // The fused kernel itself lives in fused_knn.h and is instantiated by knn_fused_0..3.hip
-// (four translation units, so that its many variants compile side by side).
+// (four translation units, so that its many variants compile side by side); knn_fused_4.hip holds
+// the pruned product kernels (blocks skip the cells out of their queries' reach) and
+// knn_fused_5.hip the stream-sharing kernels of fused_knn_share.h (single-round plans: blocks out
+// of work join unfinished streams).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -98,7 +102,7 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict_
 // threshold is tight, and it becomes tight as soon as the query has seen its near
 // neighbours.  So both sets are regrouped by nearest pivot (C reference rows taken at even
 // spacing): queries of a block then share a cell, and the block streams the reference rows
-// of that cell -- its "home" stages -- before the rest.  Any assignment gives a correct
+// of that cell and of its neighbours in the chain order -- its "home" stages -- before the rest.  Any assignment gives a correct
 // search (the result is put back in the caller's row order and row numbers); a good one
 // makes it fast.  Kernels: pivots -> cell of every row + per-block cell counts -> offsets
 // -> stable scatter into a permutation -> home stages per query block.
