@@ -8,6 +8,7 @@ O=gpurun_out/quick_$TAG.jsonl; : > $O
 run() { timeout -k 10 200 python3 bench.py --steps 5 --warmup 1 --no-cpu --no-full "$@" >> $O 2>gpurun_out/quick_err.log || { tail -3 gpurun_out/quick_err.log; exit 1; }; }
 run --workload c3
 run --workload c2
+run --workload c4
 run --workload c3 --n 125000
 run --workload c3 --n 250000
 run --workload c5shard
