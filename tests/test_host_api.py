@@ -219,3 +219,48 @@ def test_process_group_wiring_is_opt_in():
         sharded.use_process_group()
     sharded.use_process_group(enable=False)
     assert sharded.active_group() is None
+
+
+def test_stream_sharing_plan_invariants_without_gpu():
+    """Planning only: where a dense search shares its streams, every block of the grid is a stream,
+    the kernel is the sharing one, the workspace grows by the helpers' shortlists (64 keys, 64
+    pending entries and a threshold per query, `lists` times per stream) plus the queues, and
+    switching sharing off gives the plain plan back.  Several rounds, pruned searches and more than
+    64 features never share."""
+    from scmiac_amd import _hip
+
+    lib = _hip.load_library()
+    shared = 0
+    try:
+        for n, m, d in ((100_000, 100_000, 50), (50_000, 200_000, 50), (40_000, 60_000, 30), (20_000, 1_000_000, 64),
+                        (3_000, 40_000, 16), (1_000_000, 1_000_000, 50), (125_000, 1_000_000, 50), (10_412, 10_412, 30),
+                        (100_000, 100_000, 100), (2_000, 500, 8)):
+            _hip.set_sharing()
+            plan, info = _hip.knn_grid_plan(n, m, d, 30), _hip.knn_share_info(n, m, d, 30)
+            assert plan["main_query_blocks"] * plan["S"] + (plan["query_blocks"] - plan["main_query_blocks"]) * plan["St"] \
+                == plan["grid_blocks"]
+            on, off = ctypes.c_size_t(0), ctypes.c_size_t(0)
+            assert lib.scmiac_knn_workspace_size(n, m, d, 30, 0, 0, ctypes.byref(on)) == 0
+            _hip.set_sharing(lists=-1)
+            assert lib.scmiac_knn_workspace_size(n, m, d, 30, 0, 0, ctypes.byref(off)) == 0
+            assert _hip.knn_share_info(n, m, d, 30)["lists"] == 0
+            assert _hip.knn_grid_plan(n, m, d, 30) == plan          # the grid itself does not depend on sharing
+            assert _hip.knn_kernel_name(n, m, d, 30).startswith("fused_knn_kernel<")
+            _hip.set_sharing()
+            if info["lists"] == 0:
+                assert on.value == off.value and info["streams"] == 0
+                assert _hip.knn_kernel_name(n, m, d, 30).startswith("fused_knn_kernel<")
+                continue
+            shared += 1
+            assert d <= 64 and plan["main_query_blocks"] * plan["S"] <= 256 and plan["grid_blocks"] <= 512
+            assert info["streams"] == plan["grid_blocks"] and info["lists"] == 2 and info["run"] >= 2
+            assert _hip.knn_kernel_name(n, m, d, 30).startswith("fused_knn_share_kernel<")
+            rows = info["lists"] * info["streams"] * plan["queries_per_block"]
+            extra = on.value - off.value
+            assert rows * (64 * 8 + 64 * 8 + 4) <= extra <= rows * (64 * 8 + 64 * 8 + 4) + info["streams"] * (3 * 4 + 4 * 384) + 8192
+            assert _hip.knn_share_info(n, m, d, 30, splits=2)["lists"] in (0, 2)
+            assert _hip.knn_grid_plan(n, m, d, 30, mode="pruned")["prunes"] in (0, 1)
+        assert shared >= 4
+        assert lib.scmiac_knn_set_sharing(9, 0, 0) == 1 and lib.scmiac_knn_set_sharing(-2, 0, 0) == 1
+    finally:
+        _hip.set_sharing()
