@@ -255,12 +255,16 @@ SCMIAC_API int scmiac_knn_prune_stats_offset(int64_t n, int64_t m, int d, int k,
  * The result does not depend on who scored which stage.
  *   scmiac_knn_set_sharing(lists, run, min_left): lists 0 = the library's choice (two helper lists
  *     per stream where the plan is a single round), -1 = never, 1..8 = this many wherever the plan
- *     has a main region (test aid); run = stages handed out at a time (0: 4; at least 2);
+ *     has more than one block (test aid); run = stages handed out at a time (0: 4; at least 2);
  *     min_left = stages a stream must have left to be joined (0: 8).  Part of the tuning state
  *     (read once per call; scmiac_knn_set_tuning leaves these three as they are).
  *   scmiac_knn_share_info: info[4] (host) = {helper lists per stream (0: a search of this shape
  *     does not share), stages per run, min_left, streams}; *stats_offset = where such a search
- *     leaves two uint64 counters in its workspace: {streams joined, stages scored by helpers}.
+ *     leaves its counters in its workspace: two uint64 {streams joined, stages scored by helpers},
+ *     then sixteen uint64 per block of the grid {start, end of its own stream, end of the block,
+ *     stages scored for others, stages of its own stream it scored itself, first stream joined + 1,
+ *     when, streams joined, the first four streams joined + 1, stages scored in each}; times in ticks
+ *     of the constant 100 MHz clock.
  */
 SCMIAC_API int scmiac_knn_set_sharing(int lists, int run, int min_left);
 SCMIAC_API int scmiac_knn_share_info(int64_t n, int64_t m, int d, int k, int splits, int64_t *info,

@@ -326,9 +326,19 @@ def knn_share_info(n, m, d, k, splits=0, device=None, read_stats=False):
     out = dict(zip(("lists", "run", "min_left", "streams"), (int(v) for v in info)))
     if read_stats and out["lists"] > 0:
         device = device or torch.device("cuda", torch.cuda.current_device())
-        joined, stages = _ws_cache[device][off.value:off.value + 16].view(torch.int64).cpu().tolist()
-        out["joined"], out["helper_stages"] = joined, stages
+        words = _ws_cache[device][off.value:off.value + 8 * (2 + 16 * out["streams"])].view(torch.int64).cpu()
+        out["joined"], out["helper_stages"] = int(words[0]), int(words[1])
+        # per grid block: start, end of its own stream, end (ticks of the 100 MHz clock), stages scored for
+        # others, stages of its own stream it scored itself, first stream joined + 1, when, streams joined
+        out["trace"] = words[2:].view(-1, 16).numpy()  # (+ the first four streams joined + 1, stages scored in each)
     return out
+
+
+def _share_stats_offset(n, m, d, k, splits=0):
+    info = (_i64 * 4)()
+    off = ctypes.c_size_t(0)
+    _check(load_library().scmiac_knn_share_info(n, m, d, k, splits, info, ctypes.byref(off)))
+    return off.value
 
 
 def knn_grid_plan(n, m, d, k, splits=0, mode=None):

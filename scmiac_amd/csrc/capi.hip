@@ -116,7 +116,7 @@ static KnnWs knn_carve(void* ws, long long n, long long m, int d, const KnnGeome
         w.share.pub = reinterpret_cast<unsigned*>(take(sizeof(unsigned) * streams));
         w.share.claims = reinterpret_cast<unsigned*>(take(sizeof(unsigned) * streams));
         w.share_stats_offset = off;
-        w.share.stats = reinterpret_cast<unsigned long long*>(take(2 * sizeof(unsigned long long)));
+        w.share.stats = reinterpret_cast<unsigned long long*>(take((2 + 16 * streams) * sizeof(unsigned long long)));  // counters, then a trace entry per block
         w.share_ctl_bytes = off - w.share_ctl_offset;
         w.share.tau_pub = reinterpret_cast<float*>(take(sizeof(float) * streams * (size_t)g.qpb));
         w.share.row0 = g.share_row0;

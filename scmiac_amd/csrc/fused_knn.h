@@ -190,7 +190,10 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
     // (each stage then comes out of the L2 for all but the first of them), although their seed
     // passes and home stages differ in length: a block that has spent `shift` stage times on
     // those enters the rest of its chunk `shift` stages in and wraps round at the end.
-    int SN = (home != nullptr && T > 0) ? (OWN < seed_stages ? OWN : seed_stages) : 0;  // seed pass stages (own cells' head)
+    // seed pass stages (own cells' head): no more than a quarter of the stages the block is about to
+    // stream -- the short pieces of the tail would otherwise spend as long on it as on their chunk
+    int SN = (home != nullptr && T > 0) ? (OWN < seed_stages ? OWN : seed_stages) : 0;
+    { const int cap = T / 4 > 3 ? T / 4 : 3; SN = SN < cap ? SN : cap; }
     // (pruned search: the reach test needs a threshold that every query has earned among its own
     // cell's rows.  A chunk that holds those rows streams them before the test; a block whose chunk
     // does not -- one of several chunks of a query block -- looks at all of them in its seed pass.)

@@ -75,6 +75,13 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
     const int ntail = (nqb - tail.qb0) * tail.St;
     const int nstreams = nmain + ntail;
     if (tid == 0) atomicAdd(sh.started, 1u);
+    // per block, after the two counters of sh.stats: {start, end of its own stream, end, stages it scored
+    // for others, stages of its own stream it scored itself, first stream it joined + 1, when, streams
+    // joined, the first four streams joined + 1, stages scored in each}, times in ticks of the constant 100 MHz clock -- what tools/exp/share_trace.py draws its
+    // picture from
+    u64* const trace = sh.stats != nullptr ? sh.stats + 2 + 16 * (u64)blockIdx.x : nullptr;
+    u64 helped_stages = 0, n_helped = 0;
+    if (tid == 0 && trace != nullptr) trace[0] = wall_clock64();
 
     // ---- what this block works on: first its own stream, then up to MAX_HELP streams of others ----
     int v;            // the stream the item at hand draws its stages from
@@ -117,7 +124,8 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
         const int O1 = (H0 + HN < G0 + T) ? H0 + HN : G0 + T;
         const int oN = O1 > O0 ? O1 - O0 : 0;
         if (oN == 0) O0 = G0;
-        const int SN = (home != nullptr && T > 0) ? (OWN < seed_stages ? OWN : seed_stages) : 0;
+        int SN = (home != nullptr && T > 0) ? (OWN < seed_stages ? OWN : seed_stages) : 0;
+        { const int cap = T / 4 > 3 ? T / 4 : 3; SN = SN < cap ? SN : cap; }  // (as in fused_knn_kernel)
         const int rest = T - oN;
         const int shift = rest > 0 ? (SN + oN) % rest : 0;
 
@@ -371,15 +379,24 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
             atomicAdd(sh.stats, 1ull);
             atomicAdd(sh.stats + 1, (u64)done);
         }
+        if (own) { if (tid == 0 && trace != nullptr) { trace[1] = wall_clock64(); trace[4] = (u64)done; } }
+        else {
+            if (tid == 0 && trace != nullptr && n_helped < 4) { trace[8 + n_helped] = (u64)v + 1; trace[12 + n_helped] = (u64)done; }
+            helped_stages += (u64)done; ++n_helped;
+        }
 
         // ---- the next item: the published stream with the most stages left and a helper list free ----
         // (only once every block of the grid has started: a compute unit that a waiting block could
         // have is worth more to the launch than a helper)
         if (item >= MAX_HELP) break;
         if (__hip_atomic_load(sh.started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) break;
+        // Blocks run out of work in droves, and droves that all went for the one stream with the most
+        // stages left would find its lists taken and go home while the next-longest streams stay
+        // alone.  So the stages left count in units of four, and among streams of one unit every
+        // block has an order of its own (a hash of stream, block and attempt).
         int found = -1, slot = -1;
-        for (int attempt = 0; attempt < 3 && found < 0; ++attempt) {
-            unsigned best = 0u;  // (stages left, capped) << 12 | (4095 - stream): the larger the better
+        for (int attempt = 0; attempt < 6 && found < 0; ++attempt) {
+            unsigned best = 0u;  // (stages left / 4, capped) << 20 | hash << 12 | (4095 - stream): the larger the better
             for (int vv = tid; vv < nstreams; vv += NT) {
                 const unsigned p = __hip_atomic_load(sh.pub + vv, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
                 if (p == 0u) continue;
@@ -387,8 +404,9 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
                 const unsigned cl = __hip_atomic_load(sh.claims + vv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const long long left = (long long)(p - 1u) - (long long)c;
                 if (left >= (long long)sh.min_left && cl < (unsigned)sh.lists_per) {
-                    const unsigned capped = left > 0xfffffll ? 0xfffffu : (unsigned)left;
-                    const unsigned key = (capped << 12) | (unsigned)(4095 - vv);
+                    const unsigned unit = left / 4 > 0xfffll ? 0xfffu : (unsigned)(left / 4);
+                    const unsigned hash = (((unsigned)vv * 2654435761u) ^ ((unsigned)blockIdx.x * 40503u + (unsigned)attempt * 977u)) >> 24;
+                    const unsigned key = (unit << 20) | (hash << 12) | (unsigned)(4095 - vv);
                     best = key > best ? key : best;
                 }
             }
@@ -411,8 +429,10 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
             if (got < sh.lists_per) { found = cand; slot = got; }
         }
         if (found < 0) break;
+        if (tid == 0 && trace != nullptr && n_helped == 0) { trace[5] = (u64)found + 1; trace[6] = wall_clock64(); }
         v = found; hslot = slot;
     }
+    if (tid == 0 && trace != nullptr) { trace[2] = wall_clock64(); trace[3] = helped_stages; trace[7] = n_helped; }
 }
 
 #undef SCMIAC_SHARE_TEST_PREV
