@@ -253,10 +253,11 @@ SCMIAC_API int scmiac_knn_prune_stats_offset(int64_t n, int64_t m, int d, int k,
  * are handed out in runs through a counter, to its owner and to blocks that have run out of work
  * of their own; those fill shortlists of their own, which the refine pass merges like a chunk's.
  * The result does not depend on who scored which stage.
- *   scmiac_knn_set_sharing(lists, run, min_left): lists 0 = the library's choice (two helper lists
+ *   scmiac_knn_set_sharing(lists, run, min_left, order): lists 0 = the library's choice (two helper lists
  *     per stream where the plan is a single round), -1 = never, 1..8 = this many wherever the plan
  *     has more than one block (test aid); run = stages handed out at a time (0: 4; at least 2);
- *     min_left = stages a stream must have left to be joined (0: 8).  Part of the tuning state
+ *     min_left = stages a stream must have left to be joined (0: 8); order = 0 the library's choice, 1 the
+ *     tail pieces first in the grid, 2 last (A/B aid).  Part of the tuning state
  *     (read once per call; scmiac_knn_set_tuning leaves these three as they are).
  *   scmiac_knn_share_info: info[4] (host) = {helper lists per stream (0: a search of this shape
  *     does not share), stages per run, min_left, streams}; *stats_offset = where such a search
@@ -266,7 +267,7 @@ SCMIAC_API int scmiac_knn_prune_stats_offset(int64_t n, int64_t m, int d, int k,
  *     when, streams joined, the first four streams joined + 1, stages scored in each}; times in ticks
  *     of the constant 100 MHz clock.
  */
-SCMIAC_API int scmiac_knn_set_sharing(int lists, int run, int min_left);
+SCMIAC_API int scmiac_knn_set_sharing(int lists, int run, int min_left, int order);
 SCMIAC_API int scmiac_knn_share_info(int64_t n, int64_t m, int d, int k, int splits, int64_t *info,
                                      size_t *stats_offset);
 

@@ -42,7 +42,7 @@ _SIGNATURES = {
     "scmiac_knn_diag_region": ([_i64, _i64, _i32, _i32, _i32, _i32, _c.POINTER(_sz), _c.POINTER(_sz),
                                 _c.POINTER(_c.c_int)], _c.c_int),
     "scmiac_knn_prune_stats_offset": ([_i64, _i64, _i32, _i32, _i32, _c.POINTER(_sz)], _c.c_int),
-    "scmiac_knn_set_sharing": ([_i32] * 3, _c.c_int),
+    "scmiac_knn_set_sharing": ([_i32] * 4, _c.c_int),
     "scmiac_knn_share_info": ([_i64, _i64, _i32, _i32, _i32, _c.POINTER(_i64), _c.POINTER(_sz)], _c.c_int),
     "scmiac_knn_grid_plan": ([_i64, _i64, _i32, _i32, _i32, _i32, _c.POINTER(_i64)], _c.c_int),
     "scmiac_knn_kernel_name": ([_i64, _i64, _i32, _i32, _i32, _i32, _c.c_char_p, _sz], _c.c_int),
@@ -309,11 +309,11 @@ def knn_prune_stats(n, m, d, k, splits=0, device=None):
     return kept, dense
 
 
-def set_sharing(*, lists=0, run=0, min_left=0):
+def set_sharing(*, lists=0, run=0, min_left=0, order=0):
     """Stream-sharing knobs of the dense search (``set_sharing()`` resets them): ``lists`` helper
     shortlists per stream (0 the library's choice, -1 never), ``run`` stages handed out at a time,
-    ``min_left`` stages a stream must have left to be joined."""
-    _check(load_library().scmiac_knn_set_sharing(int(lists), int(run), int(min_left)))
+    ``min_left`` stages a stream must have left to be joined, ``order`` 1 / 2 the tail pieces first / last in the grid."""
+    _check(load_library().scmiac_knn_set_sharing(int(lists), int(run), int(min_left), int(order)))
 
 
 def knn_share_info(n, m, d, k, splits=0, device=None, read_stats=False):

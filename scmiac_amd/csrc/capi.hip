@@ -123,6 +123,7 @@ static KnnWs knn_carve(void* ws, long long n, long long m, int d, const KnnGeome
         w.share.lists_per = g.share;
         w.share.chunk = g.share_chunk;
         w.share.min_left = g.share_min_left;
+        w.share.tail_first = g.share_tail_first;
     }
     w.diag = reinterpret_cast<unsigned long long*>(p + off);
     w.diag_offset = off;
@@ -467,6 +468,7 @@ int scmiac_knn_set_tuning(int slots, int tail_min_rows, int no_tail, int ablate,
     {   // (the sharing knobs have a call of their own and stay as they are)
         const FusedTuning cur = knn_get_tuning();
         t.share = cur.share; t.share_chunk = cur.share_chunk; t.share_min_left = cur.share_min_left;
+        t.share_order = cur.share_order;
     }
     if (!knn_set_tuning(t))
         return fail(SCMIAC_ERR_ARG, "tuning rejected: negative value, or kernel variant %dx%dx%dx%d is not compiled",
@@ -474,12 +476,12 @@ int scmiac_knn_set_tuning(int slots, int tail_min_rows, int no_tail, int ablate,
     return SCMIAC_OK;
 }
 
-int scmiac_knn_set_sharing(int lists, int chunk, int min_left) {
+int scmiac_knn_set_sharing(int lists, int chunk, int min_left, int order) {
     FusedTuning t = knn_get_tuning();
-    t.share = lists; t.share_chunk = chunk; t.share_min_left = min_left;
+    t.share = lists; t.share_chunk = chunk; t.share_min_left = min_left; t.share_order = order;
     if (!knn_set_tuning(t))
         return fail(SCMIAC_ERR_ARG, "sharing knobs rejected: lists %d outside -1..8, run of %d stages (0 or at least 2), "
-                    "min_left %d negative", lists, chunk, min_left);
+                    "min_left %d negative, order %d outside 0..2", lists, chunk, min_left, order);
     return SCMIAC_OK;
 }
 

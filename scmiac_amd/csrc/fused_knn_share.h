@@ -86,13 +86,23 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
     // ---- what this block works on: first its own stream, then up to MAX_HELP streams of others ----
     int v;            // the stream the item at hand draws its stages from
     int hslot = -1;   // helper list of that stream this block fills; -1: the stream is its own
-    if ((int)blockIdx.x < ntail) {
-        v = nmain + (int)blockIdx.x;
-    } else {
-        // (the same dealing of consecutive query blocks to an XCD as in fused_knn_kernel)
-        int b = (int)blockIdx.x - ntail;
-        if ((b | 255) < nmain) b = (b & ~255) | ((b & 7) << 5) | ((b & 255) >> 3);
-        v = b;
+    {
+        // Order of the grid: the tail pieces first (the library's choice: what is left to balance at
+        // the end is then the finely divisible part), or the main region's whole streams first and the
+        // tail pieces as compute units fall free (a block that ends while others still wait for a
+        // compute unit goes home instead of helping, see below -- so nobody helps until the last
+        // tail piece has a compute unit, which is why this order measured worse).
+        int b = (int)blockIdx.x;
+        bool tail_block;
+        if (sh.tail_first) { tail_block = b < ntail; b = tail_block ? b : b - ntail; }
+        else { tail_block = b >= nmain; b = tail_block ? b - nmain : b; }
+        if (tail_block) {
+            v = nmain + b;
+        } else {
+            // (the same dealing of consecutive query blocks to an XCD as in fused_knn_kernel)
+            if ((b | 255) < nmain) b = (b & ~255) | ((b & 7) << 5) | ((b & 255) >> 3);
+            v = b;
+        }
     }
 
     for (int item = 0;; ++item) {
@@ -388,8 +398,15 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
         // ---- the next item: the published stream with the most stages left and a helper list free ----
         // (only once every block of the grid has started: a compute unit that a waiting block could
         // have is worth more to the launch than a helper)
+        // (One thread reads the counter and the block agrees on what it read: the counter moves
+        // while blocks end, and threads that each read it for themselves could part ways here,
+        // some leaving, some waiting at the barriers below.)
         if (item >= MAX_HELP) break;
-        if (__hip_atomic_load(sh.started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) break;
+        if (tid == 0) sh_word[1] = (int)__hip_atomic_load(sh.started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const unsigned started_now = (unsigned)__builtin_amdgcn_readfirstlane(sh_word[1]);
+        __syncthreads();
+        if (started_now < gridDim.x) break;
         // Blocks run out of work in droves, and droves that all went for the one stream with the most
         // stages left would find its lists taken and go home while the next-longest streams stay
         // alone.  So the stages left count in units of four, and among streams of one unit every

@@ -54,6 +54,7 @@ struct KnnGeometry {
     int share;
     int share_chunk;       // stages handed out at a time
     int share_min_left;    // stages a stream must have left to be worth joining
+    int share_tail_first;  // 1: the tail pieces are the first blocks of the grid
     long long share_row0;  // first helper shortlist: row share_row0 + (slot * blocks + stream) * qpb + query
 };
 
@@ -102,6 +103,7 @@ struct FusedTuning {
     int share;          // stream sharing: 0 the library's choice, -1 never, > 0 this many helper lists per stream wherever the plan allows
     int share_chunk;    // > 0: stages handed out at a time (at least 2; default 4)
     int share_min_left; // > 0: stages a stream must have left to be joined (default 8)
+    int share_order;    // 0 the library's choice, 1 tail pieces first in the grid, 2 tail pieces last
 };
 // One snapshot per C-ABI call: everything that call plans, carves and launches derives from it, so
 // a concurrent scmiac_knn_set_tuning cannot pair a geometry planned under one setting with a
@@ -154,6 +156,7 @@ struct ShareArgs {
     int lists_per;              // helper lists per stream
     int chunk;                  // stages handed out at a time (>= 2)
     int min_left;               // stages a stream must have left to be worth joining
+    int tail_first;             // 1: the tail pieces are the first blocks of the grid, 0: the last
     unsigned long long* stats;  // [2]: streams joined, stages scored by helpers (atomic adds)
 };
 

@@ -921,7 +921,9 @@ bool knn_set_tuning(const FusedTuning& t) {
     if (t.slots < 0 || t.tail_min_rows < 0 || t.ablate < 0 || t.home_rows < 0 || t.seed_rows < 0 || t.cell_rows < 0)
         return false;
     // (runs of fewer than two stages would ask for the next run before the answer to the last request is in)
-    if (t.share < -1 || t.share > 8 || t.share_chunk < 0 || t.share_chunk == 1 || t.share_min_left < 0) return false;
+    if (t.share < -1 || t.share > 8 || t.share_chunk < 0 || t.share_chunk == 1 || t.share_min_left < 0 || t.share_order < 0 ||
+        t.share_order > 2)
+        return false;
     std::lock_guard<std::mutex> lock(g_plan_mu);
     g_tuning = t;
     return true;
@@ -1107,7 +1109,7 @@ KnnGeometry knn_geometry(long long n, long long m, int d, int k, int splits, int
     // stream from the first stage to the last, and the launch would end with the slowest of them)
     // and the streams are long enough to be worth handing out in runs.  Two helper lists per
     // stream.  (Not for the diagnostic instantiation, which has no such kernel.)
-    g.share = 0; g.share_chunk = 0; g.share_min_left = 0; g.share_row0 = g.list_rows;
+    g.share = 0; g.share_chunk = 0; g.share_min_left = 0; g.share_tail_first = 0; g.share_row0 = g.list_rows;
     if (mode == 0 && !g.prune && tn.share >= 0 && !tn.diag && !(tn.ablate & (63 | 128)) && g.blocks >= 2 &&
         g.blocks <= 4096 && fused_share_compiled(g)) {
         const int chunk = tn.share_chunk > 0 ? tn.share_chunk : 4;
@@ -1116,6 +1118,7 @@ KnnGeometry knn_geometry(long long n, long long m, int d, int k, int splits, int
             g.share = tn.share > 0 ? tn.share : 2;
             g.share_chunk = chunk;
             g.share_min_left = tn.share_min_left > 0 ? tn.share_min_left : 8;
+            g.share_tail_first = tn.share_order == 2 ? 0 : 1;  // the library's choice: tail pieces first (measured)
             g.list_rows += (long long)g.share * g.blocks * g.qpb;
         }
     }

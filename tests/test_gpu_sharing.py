@@ -60,8 +60,10 @@ def test_shared_streams_give_the_oracle_table(d, unit, knobs):
     st = _check(Q, R, 30)
     _check(Q[:3072], R, 31)                 # eight query blocks exactly: no tail
     _check(Q, R, 30, splits=3)
-    sharing(lists=1, run=5, min_left=3)
+    sharing(lists=1, run=5, min_left=3, order=1)
     _check(Q[:4000], R, 30)
+    sharing(lists=3, run=2, min_left=1, order=2)
+    _check(Q[:4000], R, 31)
     sharing(lists=-1)                       # the same search without sharing: the same table
     assert _hip.knn_share_info(5000, 70000, d, 30)["lists"] == 0
     plain = _hip.knn_search(_dev(Q), _dev(R), 30)
@@ -99,22 +101,31 @@ def test_a_slow_stream_is_joined(knobs):
     assert stats["joined"] >= 1 and stats["helper_stages"] >= 4, stats
 
 
-def test_library_choice_at_a_single_round(knobs):
-    """The library's own plan: 40 000 x 60 000 is a single round of 105 streams on an MI355X, shared
-    by default; rows of a seeded sample against the oracle, the whole table against the search that
-    does not share."""
+@pytest.mark.parametrize("order", [0, 1, 2])
+def test_library_choice_at_a_single_round(order, knobs):
+    """The library's own plan at 100 000 x 100 000: 256 whole streams and 75 tail pieces on the 256
+    compute units of an MI355X -- more blocks than the GPU runs at once, so blocks end while
+    others have not started yet -- shared by default, with the tail pieces first (the default) or
+    last in the grid; rows of a seeded sample against the oracle, the whole table against the
+    search that does not share."""
     tuning, sharing = knobs
-    n, m, d = 40000, 60000, 50
+    n, m, d = 100000, 100000, 50
     Q = _clustered(51, n, d, 30)
     R = _clustered(52, m, d, 30)
+    sharing(order=order)
     info = _hip.knn_share_info(n, m, d, 30)
-    assert info["lists"] == 2 and info["streams"] >= 64
-    st = _hip.knn_search(_dev(Q), _dev(R), 30)
+    assert info["lists"] == 2 and info["streams"] >= 256
+    q, r = _dev(Q), _dev(R)
+    st = _hip.knn_search(q, r, 30)
     torch.cuda.synchronize()
+    stats = _hip.knn_share_info(n, m, d, 30, read_stats=True)
+    assert stats["joined"] >= 1                      # 331 blocks of uneven length: somebody ran out of work early
     rows = np.random.default_rng(5).choice(n, 1500, replace=False)
     idx_o, d2_o = oracle.knn_dist2(Q[rows], R, 30)
     np.testing.assert_array_equal(st.idx.cpu().numpy()[rows], idx_o)
     np.testing.assert_array_equal(st.dist2.cpu().numpy()[rows], d2_o)
+    again = _hip.knn_search(q, r, 30)               # who joins what differs from run to run; the table does not
+    assert torch.equal(again.idx, st.idx) and torch.equal(again.dist2, st.dist2)
     sharing(lists=-1)
-    plain = _hip.knn_search(_dev(Q), _dev(R), 30)
+    plain = _hip.knn_search(q, r, 30)
     assert torch.equal(plain.idx, st.idx) and torch.equal(plain.dist2, st.dist2)

@@ -58,7 +58,7 @@ def test_size_queries_and_argument_checks_without_gpu():
     # ... several rounds: the plain dense kernel
     assert _hip.knn_kernel_name(500000, 200000, 50, 30) == "fused_knn_kernel<25, 12, 320, 64, true, 0>"
     assert _hip.knn_share_info(500000, 200000, 50, 30)["lists"] == 0
-    assert lib.scmiac_knn_set_sharing(0, 1, 0) == 1 and b"run of 1" in lib.scmiac_last_error()
+    assert lib.scmiac_knn_set_sharing(0, 1, 0, 0) == 1 and b"run of 1" in lib.scmiac_last_error()
     _hip.set_sharing(lists=-1)
     try:
         assert _hip.knn_kernel_name(50000, 200000, 50, 30) == "fused_knn_kernel<25, 12, 320, 64, true, 0>"
@@ -257,10 +257,11 @@ def test_stream_sharing_plan_invariants_without_gpu():
             assert _hip.knn_kernel_name(n, m, d, 30).startswith("fused_knn_share_kernel<")
             rows = info["lists"] * info["streams"] * plan["queries_per_block"]
             extra = on.value - off.value
-            assert rows * (64 * 8 + 64 * 8 + 4) <= extra <= rows * (64 * 8 + 64 * 8 + 4) + info["streams"] * (3 * 4 + 4 * 384) + 8192
+            assert rows * (64 * 8 + 64 * 8 + 4) <= extra <= rows * (64 * 8 + 64 * 8 + 4) + info["streams"] * (3 * 4 + 4 * 384 + 16 * 8) + 8192
             assert _hip.knn_share_info(n, m, d, 30, splits=2)["lists"] in (0, 2)
             assert _hip.knn_grid_plan(n, m, d, 30, mode="pruned")["prunes"] in (0, 1)
         assert shared >= 4
-        assert lib.scmiac_knn_set_sharing(9, 0, 0) == 1 and lib.scmiac_knn_set_sharing(-2, 0, 0) == 1
+        assert lib.scmiac_knn_set_sharing(9, 0, 0, 0) == 1 and lib.scmiac_knn_set_sharing(-2, 0, 0, 0) == 1
+        assert lib.scmiac_knn_set_sharing(0, 0, 0, 3) == 1
     finally:
         _hip.set_sharing()

@@ -15,7 +15,9 @@ import bench  # noqa: E402
 for name, n, m in (("c2", None, None), ("c4", None, None), ("c2", 50000, None)):
     U, V, _, _, d = bench.make_latents(name, n, m)
     q, r = torch.from_numpy(U).cuda(), torch.from_numpy(V).cuda()
-    for label, kw in (("default", {}), ("off: lists=1 min_left=1000000", dict(lists=1, min_left=1000000))):
+    for label, kw in (("tail pieces last", dict(order=2)), ("tail pieces first", dict(order=1)),
+                      ("tail last, no joining: lists=1 min_left=1000000", dict(lists=1, min_left=1000000, order=2)),
+                      ("plain dense kernel", dict(lists=-1))):
         _hip.set_sharing(**kw)
         for _ in range(3):
             _hip.set_timing(True)
@@ -23,11 +25,19 @@ for name, n, m in (("c2", None, None), ("c4", None, None), ("c2", 50000, None)):
             ms, _ = _hip.fused_ms()
             _hip.set_timing(False)
         info = _hip.knn_share_info(q.shape[0], r.shape[0], d, 30, read_stats=True)
+        if info["lists"] == 0:
+            print(f"== {name} n={q.shape[0]} {label}: kernel {ms:.3f} ms", flush=True)
+            continue
         plan = _hip.knn_grid_plan(q.shape[0], r.shape[0], d, 30)
         tr = info["trace"].astype(np.float64)
         t0 = tr[:, 0].min()
         start, own, end = (tr[:, 0] - t0) / 100.0, (tr[:, 1] - t0) / 100.0, (tr[:, 2] - t0) / 100.0   # microseconds
         ntail = plan["grid_blocks"] - plan["main_query_blocks"] * plan["S"]
+        tail_first = kw.get("order", 0) == 1
+        if not tail_first:   # put the rows in tail-first order for the prints below
+            tr = np.concatenate([tr[plan["grid_blocks"] - ntail:], tr[:plan["grid_blocks"] - ntail]])
+            t0 = tr[:, 0].min()
+            start, own, end = (tr[:, 0] - t0) / 100.0, (tr[:, 1] - t0) / 100.0, (tr[:, 2] - t0) / 100.0
         main = slice(ntail, None)
         pct = lambda a: " ".join(f"{np.percentile(a, p):7.0f}" for p in (0, 10, 50, 90, 99, 100))
         print(f"== {name} n={q.shape[0]} {label}: kernel {ms:.3f} ms, joined {info['joined']}, helper stages {info['helper_stages']}, tail blocks {ntail}")
