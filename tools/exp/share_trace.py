@@ -12,12 +12,10 @@ sys.path.insert(0, str(ROOT))
 from scmiac_amd import _hip  # noqa: E402
 import bench  # noqa: E402
 
-for name, n, m in (("c2", None, None), ("c4", None, None), ("c2", 50000, None)):
+for name, n, m in (("c2", None, None), ("c4", None, None), ("c2", 50000, None), ("c3", 60000, 500000)):
     U, V, _, _, d = bench.make_latents(name, n, m)
     q, r = torch.from_numpy(U).cuda(), torch.from_numpy(V).cuda()
-    for label, kw in (("tail pieces last", dict(order=2)), ("tail pieces first", dict(order=1)),
-                      ("tail last, no joining: lists=1 min_left=1000000", dict(lists=1, min_left=1000000, order=2)),
-                      ("plain dense kernel", dict(lists=-1))):
+    for label, kw in (("tail pieces first", dict(order=1)), ("tail pieces last", dict(order=2)), ("plain dense kernel", dict(lists=-1))):
         _hip.set_sharing(**kw)
         for _ in range(3):
             _hip.set_timing(True)
