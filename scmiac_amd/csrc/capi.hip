@@ -97,6 +97,7 @@ static KnnWs knn_carve(void* ws, long long n, long long m, int d, const KnnGeome
         if (g.prune) {  // pruned search: distances to the pivots, cell radii, per-block stage lists, counters
             w.loc.qpd = reinterpret_cast<float*>(take(sizeof(float) * (size_t)g.cells_pad * (size_t)n));
             w.loc.crad = reinterpret_cast<unsigned*>(take(sizeof(unsigned) * (size_t)g.cells_pad));
+            w.loc.fps_sample = reinterpret_cast<float*>(take(sizeof(float) * (size_t)d * (size_t)knn_fps_sample_rows()));
             // a block's list holds at most the stages of its chunk; main and tail blocks differ in that
             const long long longest = g.chunk_rows > g.tail.chunk_rows ? g.chunk_rows : g.tail.chunk_rows;
             w.loc.order_stride = (int)(longest / g.RT + 1);

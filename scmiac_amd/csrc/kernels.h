@@ -82,6 +82,7 @@ struct LocalityWs {
     // pruned search only (NULL otherwise)
     float* qpd;             // [cells_pad][n]: lower bound of dist(query row, pivot)
     unsigned* crad;         // [cells_pad]: float bits, upper bound of max dist(reference row, its pivot)
+    float* fps_sample;      // [d][knn_fps_sample_rows()]: the farthest-point traversal's sample, feature-major
     unsigned short* order;  // [grid blocks][order_stride]: the stages a block decided to stream
     int order_stride;       // entries per block in `order`: the longest chunk's stages + 1
     unsigned long long* stats;  // [2]: stages streamed by all blocks, stages a dense search would have streamed
@@ -124,6 +125,7 @@ inline int knn_threshold_rank(int k, int d) {
 // mode: 0 dense search, 1 pruned search (honoured where the pruned kernel is compiled and the
 // locality partition applies; the dense search otherwise)
 KnnGeometry knn_geometry(long long n, long long m, int d, int k, int splits, int mode, const FusedTuning& tn);
+int knn_fps_sample_rows();       // sample rows of the pruned search's farthest-point traversal
 int knn_cell_block_rows(int d);  // rows per block of the partition kernels (their per-block histograms' granularity)
 bool fused_pruned_compiled(const KnnGeometry& g);  // is there a pruned instantiation of this geometry's variant?
 

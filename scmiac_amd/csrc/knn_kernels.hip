@@ -121,33 +121,51 @@ static int cell_rows_per_block(int d) { return d <= 64 ? 256 : (d <= 128 ? 128 :
 // radii, which the pruning bound subtracts, stay at the size of a cluster.  One block; sample row
 // s is row s * m / FPS_SAMPLE of R.
 static constexpr int FPS_SAMPLE = 4096, FPS_NT = 1024, FPS_PER = FPS_SAMPLE / FPS_NT;
+int knn_fps_sample_rows() { return FPS_SAMPLE; }
+// The traversal reads every sample row once per pivot, so the sample is first copied feature-major
+// (sampleT[i][s] = feature i of sample row s): the threads of a wave then read consecutive
+// addresses where a row-major sample would cost them 64 cache lines per load.
 __global__ __launch_bounds__(FPS_NT) void fps_pivots_kernel(const float* __restrict__ R, long long m, int d, int C,
-                                                            int* __restrict__ piv_rows) {
+                                                            int* __restrict__ piv_rows, float* __restrict__ sampleT) {
     __shared__ float pv[SCMIAC_KNN_MAX_D_INTERNAL];
     __shared__ float red_v[FPS_NT / 64];
     __shared__ int red_i[FPS_NT / 64];
     __shared__ int cur;
     const int tid = threadIdx.x;
     const long long S = m < FPS_SAMPLE ? m : FPS_SAMPLE;
+    for (long long e = tid; e < S * d; e += FPS_NT) {
+        const long long s = e / d;
+        const int i = (int)(e - s * d);
+        sampleT[(long long)i * FPS_SAMPLE + s] = R[(s * m / S) * d + i];
+    }
     float mind[FPS_PER];
 #pragma unroll
     for (int u = 0; u < FPS_PER; ++u) mind[u] = __builtin_inff();
     if (tid == 0) { cur = 0; piv_rows[0] = 0; }
-    __syncthreads();
+    __syncthreads();  // (the block's own global writes above are visible to it after the barrier)
     for (int c = 1; c <= C; ++c) {
-        const long long prow = (long long)cur * m / S;
-        for (int i = tid; i < d; i += FPS_NT) pv[i] = R[prow * d + i];
+        const int pcur = cur;
+        for (int i = tid; i < d; i += FPS_NT) pv[i] = sampleT[(long long)i * FPS_SAMPLE + pcur];
         __syncthreads();
+        float acc[FPS_PER];
+#pragma unroll
+        for (int u = 0; u < FPS_PER; ++u) acc[u] = 0.0f;
+        for (int i = 0; i < d; ++i) {
+            const float p = pv[i];
+            const float* col = sampleT + (long long)i * FPS_SAMPLE + tid;
+#pragma unroll
+            for (int u = 0; u < FPS_PER; ++u) {
+                const float t = col[u * FPS_NT] - p;  // (sample rows past S are never looked at below)
+                acc[u] = __fmaf_rn(t, t, acc[u]);
+            }
+        }
         float best = -1.0f;
         int besti = 0;
 #pragma unroll
         for (int u = 0; u < FPS_PER; ++u) {
             const long long sidx = (long long)u * FPS_NT + tid;
             if (sidx < S) {
-                const float* row = R + (sidx * m / S) * d;
-                float acc = 0.0f;
-                for (int i = 0; i < d; ++i) { const float t = row[i] - pv[i]; acc = __fmaf_rn(t, t, acc); }
-                mind[u] = fminf(mind[u], acc == acc ? acc : 0.0f);  // (NaN rows never become pivots)
+                mind[u] = fminf(mind[u], acc[u] == acc[u] ? acc[u] : 0.0f);  // (NaN rows never become pivots)
                 if (mind[u] > best) { best = mind[u]; besti = (int)sidx; }
             }
         }
@@ -1196,8 +1214,8 @@ int knn_cell_block_rows(int d) { return cell_rows_per_block(d); }
 hipError_t launch_locality(const float* Q, long long n, const float* R, long long m, int d, const KnnGeometry& g,
                            const LocalityWs& w, hipStream_t stream) {
     const int* piv_rows = nullptr;
-    if (g.prune && w.crad != nullptr) {
-        hipLaunchKernelGGL(fps_pivots_kernel, dim3(1), dim3(FPS_NT), 0, stream, R, m, d, g.cells, w.piv_rows);
+    if (g.prune && w.crad != nullptr && w.fps_sample != nullptr) {
+        hipLaunchKernelGGL(fps_pivots_kernel, dim3(1), dim3(FPS_NT), 0, stream, R, m, d, g.cells, w.piv_rows, w.fps_sample);
         piv_rows = w.piv_rows;
     }
     // the pivots as chosen (scratch copy), the leads' mutual distances, the chain, the pivots in chain order
