@@ -70,15 +70,15 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
     };
 
     // Streams: one per grid block of the plan -- (chunk, query block) of the main region, then
-    // (query block, piece) of the tail.  The tail blocks come first in the grid.
+    // (query block, piece) of the tail.
     const int nmain = tail.block0;
     const int ntail = (nqb - tail.qb0) * tail.St;
     const int nstreams = nmain + ntail;
     if (tid == 0) atomicAdd(sh.started, 1u);
-    // per block, after the two counters of sh.stats: {start, end of its own stream, end, stages it scored
-    // for others, stages of its own stream it scored itself, first stream it joined + 1, when, streams
-    // joined, the first four streams joined + 1, stages scored in each}, times in ticks of the constant 100 MHz clock -- what tools/exp/share_trace.py draws its
-    // picture from
+    // A trace entry per block, after the two counters of sh.stats: {start, end of its own stream,
+    // end, stages it scored for others, stages of its own stream it scored itself, first stream it
+    // joined + 1, when, streams joined, the first four streams joined + 1, stages scored in each};
+    // times in ticks of the constant 100 MHz clock (tools/exp/share_trace.py draws its picture from it).
     u64* const trace = sh.stats != nullptr ? sh.stats + 2 + 16 * (u64)blockIdx.x : nullptr;
     u64 helped_stages = 0, n_helped = 0;
     if (tid == 0 && trace != nullptr) trace[0] = wall_clock64();
