@@ -152,17 +152,81 @@ def _workspace(nbytes, device):
 
 
 _default_mode = "dense"
+SEARCH_MODES = ("dense", "pruned", "auto")
+
+# "auto": a probe search decides.  Sizes below which the probe (3 - 12 ms) is not worth its time or
+# its clumps would not look like query blocks (the dense search is taken: at most ~35 ms), the
+# probe's shape, and the share of the dense stream above which the pruned search no longer pays
+# (its stages are all candidate-rich: ~1.4x the time of a dense stage; measured shares are
+# below 0.15 on clustered data and above 0.95 on data without structure).
+AUTO_MIN_QUERIES = 16384
+AUTO_MIN_REFERENCES = 32768
+AUTO_MIN_PAIRS = 4e10
+AUTO_MAX_FEATURES = 64
+AUTO_PROBE_GROUPS = 8
+AUTO_PROBE_GROUP_ROWS = 384
+AUTO_PROBE_POOL = 65536
+AUTO_KEPT_LIMIT = 0.6
 
 
 def set_default_mode(mode):
-    """``"dense"`` or ``"pruned"``: how searches that do not say so themselves go through the
-    reference rows (see ``SCMIAC_KNN_PRUNED`` in the header; both give the same, exact tables).
-    Returns the previous setting."""
+    """``"dense"``, ``"pruned"`` or ``"auto"``: how searches that do not say so themselves go
+    through the reference rows (see ``SCMIAC_KNN_PRUNED`` in the header; all give the same, exact
+    tables; ``"auto"`` see :func:`choose_mode`).  Returns the previous setting."""
     global _default_mode
-    if mode not in KNN_MODES:
-        raise ValueError(f"mode must be one of {sorted(KNN_MODES)}")
+    if mode not in SEARCH_MODES:
+        raise ValueError(f"mode must be one of {sorted(SEARCH_MODES)}")
     previous, _default_mode = _default_mode, mode
     return previous
+
+
+def _mode_index(mode):
+    mode = mode or _default_mode
+    return KNN_MODES["dense" if mode == "auto" else mode]    # planning calls: auto is sized as the dense search
+
+
+def knn_kept_fraction(q, r, k, *, groups=AUTO_PROBE_GROUPS, group_rows=AUTO_PROBE_GROUP_ROWS):
+    """Share of the dense stream that the pruned search of ``q`` in ``r`` would go through,
+    measured on a probe: ``groups`` clumps of queries (evenly spaced query rows, each with the
+    ``group_rows`` - 1 queries nearest to it: what a query block of the search looks like after
+    the locality partition; a clump per query block of the probe, or blocks would mix far-apart
+    queries and their thresholds say nothing) searched in pruned mode against all of ``r``, the
+    reference rows cut into enough chunks to fill the GPU so that a probe on data that do not
+    prune is over quickly.  Waits for the GPU."""
+    n, m = q.shape[0], r.shape[0]
+    groups = max(1, min(groups, n))
+    group_rows = max(1, min(group_rows, n))
+    centres = q[torch.arange(groups, device=q.device) * (n // groups) + n // (2 * groups)]
+    score = (q * q).sum(1)[None, :] - 2.0 * (centres @ q.T)                # |q - c|^2 - |c|^2, a row per centre
+    # a radius that holds the clump with room to spare, read off at most 65 536 evenly spaced
+    # queries, so that the exact selection runs over a few thousand rows instead of all
+    pool = score[:, ::max(1, n // AUTO_PROBE_POOL)] if n > AUTO_PROBE_POOL else score
+    expect = group_rows * pool.shape[1] / n
+    radius = torch.kthvalue(pool, max(1, min(pool.shape[1], round(3 * expect + 48))), dim=1).values
+    picks = []
+    for g in range(groups):
+        near = torch.nonzero(score[g] <= radius[g]).squeeze(1)
+        if near.numel() < group_rows:
+            near = torch.arange(n, device=q.device)
+        picks.append(near[torch.topk(score[g][near], group_rows, largest=False, sorted=False).indices])
+    probe = q[torch.cat(picks)].contiguous()
+    splits = max(1, min(256 // groups, m // 8192))
+    knn_search(probe, r, k, mode="pruned", exact_fallback=False, splits=splits)
+    kept, dense = knn_prune_stats(probe.shape[0], m, q.shape[1], k, splits=splits, device=q.device)
+    return kept / dense if dense > 0 else 1.0
+
+
+def choose_mode(q, r, k):
+    """``"dense"`` or ``"pruned"`` for this search (device tensors): the dense search for sizes at
+    which a probe would cost more than it can save and for rows wider than the pruned kernels
+    take, else the pruned search if :func:`knn_kept_fraction` says that it goes through less than
+    ``AUTO_KEPT_LIMIT`` of the stream.  Either answer gives the same table."""
+    n, d = q.shape
+    m = r.shape[0]
+    if (n < AUTO_MIN_QUERIES or m < AUTO_MIN_REFERENCES or float(n) * m < AUTO_MIN_PAIRS or d > AUTO_MAX_FEATURES
+            or k + 1 > 64):
+        return "dense"
+    return "pruned" if knn_kept_fraction(q, r, k) < AUTO_KEPT_LIMIT else "dense"
 
 
 def knn_search(q, r, k, *, col_offset=0, state=None, splits=0, exact_fallback=True, mode=None):
@@ -170,15 +234,21 @@ def knn_search(q, r, k, *, col_offset=0, state=None, splits=0, exact_fallback=Tr
 
     Returns a :class:`KnnState`; pass it back as ``state`` with another
     reference block (and that block's ``col_offset``) to extend the search.
-    ``mode``: ``"dense"`` / ``"pruned"`` (None: :func:`set_default_mode`'s, initially dense).
+    ``mode``: ``"dense"`` / ``"pruned"`` / ``"auto"`` (None: :func:`set_default_mode`'s, initially
+    dense; ``"auto"`` runs a probe first and waits for it, see :func:`choose_mode`).
     """
     lib = require_gpu()
-    mode_i = KNN_MODES[mode or _default_mode]
+    mode = mode or _default_mode
+    if mode not in SEARCH_MODES:
+        raise ValueError(f"mode must be one of {sorted(SEARCH_MODES)}")
     device = q.device if isinstance(q, torch.Tensor) and q.is_cuda else torch.device("cuda", torch.cuda.current_device())
     q = _dev_f32(q, device)
     r = _dev_f32(r, device)
     if q.dim() != 2 or r.dim() != 2 or q.shape[1] != r.shape[1]:
         raise ValueError("q and r must be 2-D with the same number of columns")
+    if mode == "auto":
+        mode = choose_mode(q, r, k)
+    mode_i = KNN_MODES[mode]
     n, d = q.shape
     m = r.shape[0]
     merge = 0 if state is None else 1
@@ -292,7 +362,7 @@ def knn_diag(n, m, d, k, splits=0, device=None, mode=None):
     """Per-wave counters of the last fused kernel (needs ``set_tuning(diag=True)`` at search time):
     int64 array [waves, 16]."""
     off, nbytes, waves = ctypes.c_size_t(0), ctypes.c_size_t(0), ctypes.c_int(0)
-    _check(load_library().scmiac_knn_diag_region(n, m, d, k, splits, KNN_MODES[mode or _default_mode],
+    _check(load_library().scmiac_knn_diag_region(n, m, d, k, splits, _mode_index(mode),
                                                  ctypes.byref(off), ctypes.byref(nbytes), ctypes.byref(waves)))
     device = device or torch.device("cuda", torch.cuda.current_device())
     ws = _ws_cache[device]
@@ -344,7 +414,7 @@ def _share_stats_offset(n, m, d, k, splits=0):
 def knn_grid_plan(n, m, d, k, splits=0, mode=None):
     """Grid layout of the fused kernel for this problem (planning only: no kernel runs)."""
     plan = (_i64 * 10)()
-    _check(load_library().scmiac_knn_grid_plan(n, m, d, k, splits, KNN_MODES[mode or _default_mode], plan))
+    _check(load_library().scmiac_knn_grid_plan(n, m, d, k, splits, _mode_index(mode), plan))
     names = ("query_blocks", "queries_per_block", "S", "chunk_rows", "main_query_blocks", "St",
              "tail_chunk_rows", "grid_blocks", "cells", "prunes")
     return dict(zip(names, (int(v) for v in plan)))
@@ -353,7 +423,7 @@ def knn_grid_plan(n, m, d, k, splits=0, mode=None):
 def knn_kernel_name(n, m, d, k, splits=0, mode=None):
     """Instantiation of the fused kernel a search of this shape launches (planning only)."""
     buf = ctypes.create_string_buffer(128)
-    _check(load_library().scmiac_knn_kernel_name(n, m, d, k, splits, KNN_MODES[mode or _default_mode], buf, len(buf)))
+    _check(load_library().scmiac_knn_kernel_name(n, m, d, k, splits, _mode_index(mode), buf, len(buf)))
     return buf.value.decode()
 
 

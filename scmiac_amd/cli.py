@@ -212,9 +212,10 @@ def build_parser() -> argparse.ArgumentParser:
     train.add_argument("--no-balanced-sampler", dest="balanced_sampler", action="store_false", default=True,
                        help="draw anchor batches uniformly instead of weighting by 1 / cell-type frequency")
     # two options the reference does not have (its scripts never pass them; the defaults keep its behaviour)
-    train.add_argument("--search-mode", choices=["dense", "pruned"], default="dense",
-                       help="how the exact k-NN search goes through the cells: every query against every cell, or "
-                            "only the pivot cells that can hold a neighbour (same tables, much faster on clustered data)")
+    train.add_argument("--search-mode", choices=["dense", "pruned", "auto"], default="dense",
+                       help="how the exact k-NN search goes through the cells: every query against every cell, "
+                            "only the pivot cells that can hold a neighbour (same tables, much faster on clustered data), "
+                            "or whichever of the two a short probe search favours")
     train.add_argument("--device-consumer", action="store_true", default=False,
                        help="with scMIAC installed: feed its training loop from device-resident loaders and the fused "
                             "anchor loss of this package instead of its DataLoaders and eager loss")

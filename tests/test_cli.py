@@ -25,6 +25,10 @@ def test_train_flags_and_defaults():
     assert (args.mode, args.hidden_dims, args.balanced_sampler, args.k_anchor) == ("v", [64, 32], False, 7)
     with pytest.raises(SystemExit):
         cli.build_parser().parse_args(["train", "--mode", "d"])
+    for mode in ("dense", "pruned", "auto"):
+        assert cli.build_parser().parse_args(["train", "--search-mode", mode]).search_mode == mode
+    with pytest.raises(SystemExit):
+        cli.build_parser().parse_args(["train", "--search-mode", "fast"])
 
 
 def test_missing_required_argument_message():

@@ -170,7 +170,7 @@ def test_pruned_mode_on_structureless_data_and_where_it_does_not_apply():
     Qw, _ = _clustered(3, 3000, 100, 10)
     Rw, _ = _clustered(4, 20000, 100, 10)
     _check(Qw, Rw, 30, mode="pruned")
-    with pytest.raises(KeyError):
+    with pytest.raises(ValueError):
         _hip.knn_search(_dev(Q), _dev(R), 30, mode="sparse")
 
 

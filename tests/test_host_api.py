@@ -265,3 +265,22 @@ def test_stream_sharing_plan_invariants_without_gpu():
         assert lib.scmiac_knn_set_sharing(0, 0, 0, 3) == 1
     finally:
         _hip.set_sharing()
+
+
+def test_search_modes_without_gpu():
+    """The mode names the host layer takes; "auto" is planned as the dense search (what it falls
+    back to), and sizes at which a probe cannot pay never reach the GPU."""
+    import torch
+    from scmiac_amd import _hip
+    assert _hip.SEARCH_MODES == ("dense", "pruned", "auto")
+    previous = _hip.set_default_mode("auto")
+    try:
+        assert _hip._mode_index(None) == 0 and _hip._mode_index("pruned") == 1 and _hip._mode_index("dense") == 0
+        assert _hip.knn_grid_plan(100000, 100000, 50, 30) == _hip.knn_grid_plan(100000, 100000, 50, 30, mode="dense")
+    finally:
+        assert _hip.set_default_mode(previous) == "auto"
+    with pytest.raises(ValueError):
+        _hip.set_default_mode("fast")
+    for n, m, d, k in ((2000, 10 ** 6, 50, 30), (10 ** 6, 20000, 50, 30), (10 ** 5, 10 ** 5, 50, 30),
+                       (10 ** 6, 10 ** 6, 100, 30), (10 ** 6, 10 ** 6, 50, 70)):
+        assert _hip.choose_mode(torch.empty((n, d), device="meta"), torch.empty((m, d), device="meta"), k) == "dense"
