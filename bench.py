@@ -23,7 +23,8 @@ Rank 0 prints one JSON line.  Next to the headline it carries
                   timed on this box's host cores on a bounded sample of query rows;
                   the same rows double as the parity check of the GPU result
   full_search  -- all four tables + MNN + SNN score + label filter (one anchor search)
-  pruned_exact_search -- the same table with the opt-in pivot-pruning experiment (exact, not dense)
+  pruned_exact_search -- the same table in the pruned mode (exact, not the dense contraction), and what
+                  mode="auto" of the host layer picks for this workload and takes, probe included
   pcie_inclusive -- one table with inputs starting and the result ending in host memory
 """
 from __future__ import annotations
@@ -502,6 +503,15 @@ def pruned_search(q_dev, r_dev, k, dense):
     kept, dense_stages = _hip.knn_prune_stats(n, m, d, k)
     frac = kept / max(dense_stages, 1)
     kernel_ms = fused_ms / max(launches, 1)
+    # the host layer's own choice between the two modes: a probe search first, then the search
+    choice = _hip.choose_mode(q_dev, r_dev, k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    auto = _hip.knn_search(q_dev, r_dev, k, mode="auto")
+    torch.cuda.synchronize()
+    auto_dt = time.perf_counter() - t0
+    auto_mode = {"picks": choice, "ms_per_table_with_probe": round(auto_dt * 1e3, 3),
+                 "identical_to_dense_search": bool(torch.equal(auto.idx, dense.idx) and torch.equal(auto.dist2, dense.dist2))}
     # the contraction the kernel still performed: kept share of 2 N M d, over the kernel's time
     streamed_tflops = 2.0 * n * m * d * frac / (kernel_ms * 1e-3) / 1e12
     return {"ms_per_table": round(dt * 1e3, 3), "cells_per_s": round(n / dt, 1),
@@ -510,6 +520,7 @@ def pruned_search(q_dev, r_dev, k, dense):
             "kept_stage_fraction": round(frac, 4),
             "mfma_frac_on_streamed_stages": round(streamed_tflops / FP32_MFMA_PEAK_TFLOPS, 4),
             "identical_to_dense_search": bool(torch.equal(st.idx, dense.idx) and torch.equal(st.dist2, dense.dist2)),
+            "auto_mode": auto_mode,
             "note": "scmiac_knn_search(mode = SCMIAC_KNN_PRUNED): exact pruning by pivot cells; skips most of the dense "
                     "contraction on clustered data, so it has no roofline of its own (kernel_ms includes the blocks' "
                     "planning; ms_per_table the choice of pivots and the partition)"}
