@@ -52,9 +52,9 @@ SCMIAC_API const char *scmiac_last_error(void);
  *                      inequality, with the rounding-error slack of the search's own certificate).
  *                      Many times faster on clustered data (latent embeddings of cell atlases);
  *                      on data without structure every cell stays within reach and the search
- *                      costs what the dense one costs plus the choice of pivots.  Available up to
- *                      64 features and from 16 384 reference / 2 048 query rows on; other shapes
- *                      run dense.  No counterpart in the reference (its index, pynndescent, prunes
+ *                      costs what the dense one costs plus the choice of pivots.  Available from
+ *                      16 384 reference / 2 048 query rows on (any width the search takes); other
+ *                      shapes run dense.  No counterpart in the reference (its index, pynndescent, prunes
  *                      approximately; this is exact).
  */
 #define SCMIAC_KNN_DENSE 0

@@ -162,9 +162,7 @@ SEARCH_MODES = ("dense", "pruned", "auto")
 AUTO_MIN_QUERIES = 16384
 AUTO_MIN_REFERENCES = 32768
 AUTO_MIN_PAIRS = 4e10
-AUTO_MAX_FEATURES = 64
 AUTO_PROBE_GROUPS = 8
-AUTO_PROBE_GROUP_ROWS = 384
 AUTO_PROBE_POOL = 65536
 AUTO_KEPT_LIMIT = 0.6
 
@@ -185,16 +183,19 @@ def _mode_index(mode):
     return KNN_MODES["dense" if mode == "auto" else mode]    # planning calls: auto is sized as the dense search
 
 
-def knn_kept_fraction(q, r, k, *, groups=AUTO_PROBE_GROUPS, group_rows=AUTO_PROBE_GROUP_ROWS):
+def knn_kept_fraction(q, r, k, *, groups=AUTO_PROBE_GROUPS, group_rows=None):
     """Share of the dense stream that the pruned search of ``q`` in ``r`` would go through,
     measured on a probe: ``groups`` clumps of queries (evenly spaced query rows, each with the
     ``group_rows`` - 1 queries nearest to it: what a query block of the search looks like after
-    the locality partition; a clump per query block of the probe, or blocks would mix far-apart
+    the locality partition; ``group_rows`` is the number of queries in a block of the pruned
+    kernel for this width -- a clump per query block of the probe, or blocks would mix far-apart
     queries and their thresholds say nothing) searched in pruned mode against all of ``r``, the
     reference rows cut into enough chunks to fill the GPU so that a probe on data that do not
     prune is over quickly.  Waits for the GPU."""
     n, m = q.shape[0], r.shape[0]
     groups = max(1, min(groups, n))
+    if group_rows is None:
+        group_rows = knn_grid_plan(n, m, q.shape[1], k, mode="pruned")["queries_per_block"]
     group_rows = max(1, min(group_rows, n))
     centres = q[torch.arange(groups, device=q.device) * (n // groups) + n // (2 * groups)]
     score = (q * q).sum(1)[None, :] - 2.0 * (centres @ q.T)                # |q - c|^2 - |c|^2, a row per centre
@@ -218,13 +219,12 @@ def knn_kept_fraction(q, r, k, *, groups=AUTO_PROBE_GROUPS, group_rows=AUTO_PROB
 
 def choose_mode(q, r, k):
     """``"dense"`` or ``"pruned"`` for this search (device tensors): the dense search for sizes at
-    which a probe would cost more than it can save and for rows wider than the pruned kernels
-    take, else the pruned search if :func:`knn_kept_fraction` says that it goes through less than
+    which a probe would cost more than it can save (and for more neighbours than one search
+    returns), else the pruned search if :func:`knn_kept_fraction` says that it goes through less than
     ``AUTO_KEPT_LIMIT`` of the stream.  Either answer gives the same table."""
     n, d = q.shape
     m = r.shape[0]
-    if (n < AUTO_MIN_QUERIES or m < AUTO_MIN_REFERENCES or float(n) * m < AUTO_MIN_PAIRS or d > AUTO_MAX_FEATURES
-            or k + 1 > 64):
+    if n < AUTO_MIN_QUERIES or m < AUTO_MIN_REFERENCES or float(n) * m < AUTO_MIN_PAIRS or k + 1 > 64:
         return "dense"
     return "pruned" if knn_kept_fraction(q, r, k) < AUTO_KEPT_LIMIT else "dense"
 

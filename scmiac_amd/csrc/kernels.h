@@ -191,9 +191,12 @@ int fused_occupancy_tu0(const KnnGeometry& g);
 int fused_occupancy_tu1(const KnnGeometry& g);
 int fused_occupancy_tu2(const KnnGeometry& g);
 int fused_occupancy_tu3(const KnnGeometry& g);
-// pruned product instantiations (the library's own variants up to 64 features): a unit of their own
+// pruned product instantiations of the library's own variants: units of their own (4: up to 64
+// features, 6: wider rows)
 hipError_t launch_fused_tu4(const KnnGeometry& g, const FusedLaunch& a);
 bool fused_pruned_compiled_tu4(const KnnGeometry& g);
+hipError_t launch_fused_tu6(const KnnGeometry& g, const FusedLaunch& a);
+bool fused_pruned_compiled_tu6(const KnnGeometry& g);
 // stream-sharing instantiations (the same variants): a unit of their own
 hipError_t launch_fused_tu5(const KnnGeometry& g, const FusedLaunch& a);
 bool fused_share_compiled_tu5(const KnnGeometry& g);

@@ -992,7 +992,7 @@ static int fused_concurrent_blocks(const KnnGeometry& g) {
     return slots;
 }
 
-bool fused_pruned_compiled(const KnnGeometry& g) { return fused_pruned_compiled_tu4(g); }
+bool fused_pruned_compiled(const KnnGeometry& g) { return fused_pruned_compiled_tu4(g) || fused_pruned_compiled_tu6(g); }
 static bool fused_share_compiled(const KnnGeometry& g) { return fused_share_compiled_tu5(g); }
 
 KnnGeometry knn_geometry(long long n, long long m, int d, int k, int splits, int mode, const FusedTuning& tn) {
@@ -1272,7 +1272,7 @@ hipError_t launch_fused(const KnnGeometry& g, const FusedTuning& tn, const float
                         unsigned long long* diag, hipStream_t stream) {
     uint2* pend_g = static_cast<uint2*>(pend_g_);
     // Three instantiations of every variant: the product kernel (dense), the pruned product kernel
-    // (library variants up to 64 features) and a diagnostic one that carries per-wave counters,
+    // (library variants) and a diagnostic one that carries per-wave counters,
     // the ablations (tuning bits: 1 no selection, 2 no staging, 4 no barrier, 8 empty candidate
     // path, 16 candidate arithmetic only, 32 no seed pass, 128 no per-subtile test) and the pruning code as well.
     const int ablate = tn.ablate & (63 | 128);
@@ -1280,7 +1280,7 @@ hipError_t launch_fused(const KnnGeometry& g, const FusedTuning& tn, const float
     const int kind = (diag != nullptr || ablate != 0) ? 1 : (prune.qpd != nullptr ? 2 : (g.share > 0 && share.cursor != nullptr ? 3 : 0));
     const FusedLaunch a{Qp, Rp, rnorm, lists, pend_g, n, kt, ablate, kind, home, tau0, tau_out, prune, share, diag, stream};
     for (auto launch : {launch_fused_tu0, launch_fused_tu1, launch_fused_tu2, launch_fused_tu3, launch_fused_tu4,
-                        launch_fused_tu5}) {
+                        launch_fused_tu5, launch_fused_tu6}) {
         const hipError_t e = launch(g, a);
         if (e != hipErrorNotFound) return e;  // hipErrorNotFound: the variant (of this kind) is not that file's
     }

@@ -157,7 +157,7 @@ def test_pruned_search_stays_exact(d, unit, tuning):
 
 def test_pruned_mode_on_structureless_data_and_where_it_does_not_apply():
     """No clusters: every cell stays within reach, the table is still the oracle's.  Shapes the
-    pruned kernel does not serve (few rows, more than 64 features) run the dense search."""
+    pruned kernel does not serve (too few rows for a partition) run the dense search."""
     rng = np.random.default_rng(17)
     Q = rng.normal(size=(3000, 20)).astype(np.float32)
     R = rng.normal(size=(20000, 20)).astype(np.float32)
@@ -166,12 +166,31 @@ def test_pruned_mode_on_structureless_data_and_where_it_does_not_apply():
     assert kept > 0.9 * dense
     assert _hip.knn_grid_plan(500, 3000, 20, 30, mode="pruned")["prunes"] == 0
     _check(Q[:500], R[:3000], 30, mode="pruned")
-    assert _hip.knn_grid_plan(3000, 20000, 100, 30, mode="pruned")["prunes"] == 0
-    Qw, _ = _clustered(3, 3000, 100, 10)
-    Rw, _ = _clustered(4, 20000, 100, 10)
-    _check(Qw, Rw, 30, mode="pruned")
     with pytest.raises(ValueError):
         _hip.knn_search(_dev(Q), _dev(R), 30, mode="sparse")
+
+
+@pytest.mark.parametrize("d", [72, 100, 128, 160, 192, 200, 224, 256])
+def test_pruned_search_serves_wide_rows(d):
+    """Rows of more than 64 features (the widths of filter_anchor's searches among them): the pruned
+    kernels of the wide variants skip most of the stream on clustered data and return the oracle's
+    table, which is also the dense search's."""
+    Q, _ = _clustered(23, 3000, d, 10)
+    R, _ = _clustered(24, 40000, d, 10)
+    R[700:730] = R[5]
+    Q[:4] = R[5]
+    assert _hip.knn_grid_plan(3000, 40000, d, 30, mode="pruned")["prunes"] == 1
+    assert _hip.knn_kernel_name(3000, 40000, d, 30, mode="pruned").endswith(", 2>")
+    st = _check(Q, R, 30, mode="pruned")
+    kept, dense = _hip.knn_prune_stats(3000, 40000, d, 30)
+    assert 0 < kept < 0.5 * dense, (kept, dense)
+    plain = _hip.knn_search(_dev(Q), _dev(R), 30, mode="dense")
+    assert torch.equal(plain.idx, st.idx) and torch.equal(plain.dist2, st.dist2)
+    _check(Q[:2900], R, 31, mode="pruned", splits=3)
+    rng = np.random.default_rng(d)          # no clusters: nothing to skip, the same table
+    Qn = rng.normal(size=(2500, d)).astype(np.float32)
+    Rn = rng.normal(size=(20000, d)).astype(np.float32)
+    _check(Qn, Rn, 30, mode="pruned")
 
 
 @pytest.mark.parametrize("d", [100, 128, 200, 256])

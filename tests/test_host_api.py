@@ -49,7 +49,10 @@ def test_size_queries_and_argument_checks_without_gpu():
     assert plan["S"] == 1 and plan["St"] == 1 and plan["grid_blocks"] == plan["query_blocks"]   # one block per query block
     assert _hip.knn_grid_plan(50000, 200000, 50, 30, mode="pruned")["prunes"] == 1
     assert _hip.knn_grid_plan(50000, 200000, 50, 30, mode="dense")["prunes"] == 0
-    assert _hip.knn_grid_plan(50000, 200000, 100, 30, mode="pruned")["prunes"] == 0   # beyond 64 features: dense
+    for d in (100, 200, 256):   # wide rows prune too (kernels of their own)
+        assert _hip.knn_grid_plan(50000, 200000, d, 30, mode="pruned")["prunes"] == 1
+        assert _hip.knn_kernel_name(50000, 200000, d, 30, mode="pruned").endswith(", 2>")
+    assert _hip.knn_grid_plan(1000, 200000, 50, 30, mode="pruned")["prunes"] == 0      # too few queries for a partition: dense
     assert _hip.knn_grid_plan(50000, 200000, 100, 30)["cells"] == 195                # ... but partitioned
     assert _hip.knn_kernel_name(50000, 200000, 50, 30, mode="pruned") == "fused_knn_kernel<25, 12, 320, 64, true, 2>"
     # 131 query blocks on 256 compute units: a single round, whose streams are shared ...
@@ -282,5 +285,5 @@ def test_search_modes_without_gpu():
     with pytest.raises(ValueError):
         _hip.set_default_mode("fast")
     for n, m, d, k in ((2000, 10 ** 6, 50, 30), (10 ** 6, 20000, 50, 30), (10 ** 5, 10 ** 5, 50, 30),
-                       (10 ** 6, 10 ** 6, 100, 30), (10 ** 6, 10 ** 6, 50, 70)):
+                       (10 ** 6, 10 ** 6, 50, 70)):
         assert _hip.choose_mode(torch.empty((n, d), device="meta"), torch.empty((m, d), device="meta"), k) == "dense"
