@@ -44,7 +44,7 @@ def main():
         m = int(rng.integers(1, a.max_m))
         knobs, blocks = {}, 1
         if a.locality:
-            d = int(rng.choice([2, 7, 16, 30, 31, 33, 40, 50, 51, 64, 64, 65, 100, 128, 200, 256]))
+            d = int(rng.choice([2, 7, 16, 30, 31, 33, 40, 50, 51, 64, 64, 65, 80, 100, 128, 161, 200, 224, 256]))
             n, m = int(rng.integers(2048, a.max_n)), int(rng.integers(16384, a.max_m))
             if rng.random() < 0.5:
                 knobs.update(slots=int(rng.choice([4, 8, 24])), tail_min_rows=int(rng.choice([512, 1024, 4096])))
