@@ -136,6 +136,7 @@ class KnnState:
         self.uncertified_rows = torch.empty((max(n, 1),), dtype=torch.int32, device=device)
         self.n_uncertified = torch.zeros((1,), dtype=torch.int32, device=device)
         self.blocks = 0
+        self.auto_mode = None  # what mode="auto" picked for the first reference block
 
 
 _ws_cache = {}
@@ -235,7 +236,8 @@ def knn_search(q, r, k, *, col_offset=0, state=None, splits=0, exact_fallback=Tr
     Returns a :class:`KnnState`; pass it back as ``state`` with another
     reference block (and that block's ``col_offset``) to extend the search.
     ``mode``: ``"dense"`` / ``"pruned"`` / ``"auto"`` (None: :func:`set_default_mode`'s, initially
-    dense; ``"auto"`` runs a probe first and waits for it, see :func:`choose_mode`).
+    dense; ``"auto"`` runs a probe first and waits for it, see :func:`choose_mode`; when a search is
+    extended block by block, the first block's choice holds for the rest).
     """
     lib = require_gpu()
     mode = mode or _default_mode
@@ -246,8 +248,11 @@ def knn_search(q, r, k, *, col_offset=0, state=None, splits=0, exact_fallback=Tr
     r = _dev_f32(r, device)
     if q.dim() != 2 or r.dim() != 2 or q.shape[1] != r.shape[1]:
         raise ValueError("q and r must be 2-D with the same number of columns")
-    if mode == "auto":
-        mode = choose_mode(q, r, k)
+    if mode == "auto":  # a search over several reference blocks keeps what its first block was given
+        mode = getattr(state, "auto_mode", None) or choose_mode(q, r, k)
+        chosen = mode
+    else:
+        chosen = None
     mode_i = KNN_MODES[mode]
     n, d = q.shape
     m = r.shape[0]
@@ -265,6 +270,8 @@ def knn_search(q, r, k, *, col_offset=0, state=None, splits=0, exact_fallback=Tr
                                      _ptr(state.uncertified_rows), _ptr(state.n_uncertified),
                                      1 if exact_fallback else 0, _ptr(ws), ws.numel(), _stream()))
     state.blocks += 1
+    if chosen is not None:
+        state.auto_mode = chosen
     return state
 
 

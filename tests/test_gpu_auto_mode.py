@@ -52,6 +52,7 @@ def test_auto_picks_the_mode_the_data_favour(kind, expect, small_probe):
     for lo, hi in ((0, 50000), (50000, m)):
         merged = _hip.knn_search(q, r[lo:hi], k, col_offset=lo, state=merged)
     assert torch.equal(merged.idx, st.idx) and torch.equal(merged.dist2, st.dist2)
+    assert merged.auto_mode == _hip.choose_mode(q, r[:50000], k)     # the first block's choice, kept for the second
 
 
 def test_small_searches_are_not_probed():
