@@ -181,7 +181,8 @@ __attribute__((amdgpu_waves_per_eu((NW_ >= 8 ? NW_ / 4 : 2), (NW_ >= 8 ? NW_ / 4
                 float nt = flush_query<HCAP, true>(c0, c1, pend_w + q * PCAP, lists_w + (long long)q * 64,
                                                    (inited >> q) & 1u, lane, kt);
                 inited |= 1u << q;
-                if (j == q) { tau = fminf(nt, tau_max); tau_hi = widen(tau); pcnt = 0u; }
+                // (never above the threshold the query had: a list of fewer than kt entries says nothing)
+                if (j == q) { tau = fminf(tau, fminf(nt, tau_max)); tau_hi = widen(tau); pcnt = 0u; }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         };
