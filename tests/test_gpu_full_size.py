@@ -128,3 +128,31 @@ def test_ring_workload_one_rank_share_in_eight_blocks():
         "uncertified_after_last_block": n_unc,
         "single_stream": {"fused_ms": round(ms_whole, 3),
                           "frac_of_fp32_mfma_peak": round(2.0 * n * m * d / (ms_whole * 1e-3) / 157.3e12, 4)}})
+
+
+def test_no_pruned_block_streams_everything():
+    """A pruned block plans its stream from its queries' thresholds when its home stages are nearly
+    done.  A merge of pending candidates must not loosen a threshold that the seed pass has set (a
+    shortlist of fewer than kt entries says nothing yet): with 256 features (kt = k + 24) a query
+    caught between its first merge and its second would otherwise carry the ceiling, its reach
+    would cover every cell and its block -- one of 782 -- would stream all 7 813 stages while
+    the launch waits.  Per-block stage counts from the diagnostic instantiation's counters."""
+    U, V, _, _, d = bench.make_latents("wide256")
+    n, m, k = U.shape[0], V.shape[0], 30
+    q, r = torch.from_numpy(U).cuda(), torch.from_numpy(V).cuda()
+    try:
+        _hip.set_tuning(diag=True)
+        st = _hip.knn_search(q, r, k, mode="pruned")
+        torch.cuda.synchronize()
+        plan = _hip.knn_grid_plan(n, m, d, k, mode="pruned")
+        assert plan["prunes"] == 1
+        waves = plan["queries_per_block"] // 32
+        stages = _hip.knn_diag(n, m, d, k, mode="pruned").reshape(-1, waves, 16)[:, 0, 13]
+    finally:
+        _hip.set_tuning()
+    assert len(stages) == plan["grid_blocks"]
+    assert stages.max() <= 4 * np.median(stages), (int(stages.max()), float(np.median(stages)))
+    rows = np.random.default_rng(9).choice(n, 400, replace=False)
+    idx_o, d2_o = oracle.knn_dist2(U[rows], V, k)
+    np.testing.assert_array_equal(st.idx.cpu().numpy()[rows], idx_o)
+    np.testing.assert_array_equal(st.dist2.cpu().numpy()[rows], d2_o)
