@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 look at the usual shapes after the library restructuring: dense bench lines (quick_bench),
+# A look at the usual shapes after the library restructuring: dense bench lines (quick_bench),
 # the wide-row workloads with the partition, and pruned against dense.
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $R

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 profile battery, one group per gpurun call:  tools/gpu_r03_profiles.sh a|b|c|d
+# Profile battery of the twelve bench shapes, one group per gpurun call:  tools/gpu_r03_profiles.sh a|b|c|d
 # Summaries land under gpurun_out/profiles/ (copy into profiles/ and commit).
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $R
