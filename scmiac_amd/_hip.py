@@ -213,6 +213,8 @@ def knn_kept_fraction(q, r, k, *, groups=AUTO_PROBE_GROUPS, group_rows=None):
         picks.append(near[torch.topk(score[g][near], group_rows, largest=False, sorted=False).indices])
     probe = q[torch.cat(picks)].contiguous()
     splits = max(1, min(256 // groups, m // 8192))
+    if not knn_grid_plan(probe.shape[0], m, q.shape[1], k, splits=splits, mode="pruned")["prunes"]:
+        return 1.0  # a shape the pruned kernels do not serve: the search would be the dense one anyway
     knn_search(probe, r, k, mode="pruned", exact_fallback=False, splits=splits)
     kept, dense = knn_prune_stats(probe.shape[0], m, q.shape[1], k, splits=splits, device=q.device)
     return kept / dense if dense > 0 else 1.0
